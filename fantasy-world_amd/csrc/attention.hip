@@ -1,0 +1,319 @@
+// Fused non-causal attention forward (flash style, fp32 online softmax) for gfx950, head_dim 64/96/128.
+//
+// Work-group = 8 waves (512 threads) = 256 query rows of one (batch, head); each wave owns 32 query rows.
+// Per 64-key tile:
+//   S^T[key][q]  = K_tile * Q^T      "swapped" QK^T: v_mfma_f32_32x32x16_bf16 with A = K rows, B = Q rows, so the
+//                                    accumulator column (lane&31) is the QUERY: a lane owns one query's scores and
+//                                    the running max / sum are lane-local (one cross-half exchange per tile).
+//   O^T[d][q]   += Vt_tile * P^T     A = Vt rows (d), B = P^T taken straight from the score registers.
+// The B-operand k-slot (lane>>5, j) of the PV MFMA receives the score register 8*s+j, whose key index inside a
+// 32-key block is swap_bits_2_3(16*s + 8*(lane>>5) + j) (32x32 C/D layout: row = (r&3)+8*(r>>2)+4*(lane>>5)).
+// fw_v_transpose bakes exactly that permutation into Vt's key axis, so no cross-lane shuffle is needed between
+// the two MFMAs and every LDS fragment read is a conflict-free ds_read_b128:
+//   K tile  : 64 rows x 256 B (row stride fixed at 256 B, hd/8 valid 16-B chunks), chunk ^= row&15
+//   Vt tile : hd rows x 128 B, chunk ^= (row>>1)&7
+// Both tiles are filled with global_load_lds_dwordx4 (swizzle applied on the source address), double buffered,
+// one barrier per tile.  Work-groups are ordered so that one XCD works on one head at a time (K/V stay in its L2).
+#include "fw_common.h"
+
+namespace {
+
+constexpr int QB = 256;      // query rows per work-group
+constexpr int KVB = 64;      // keys per tile
+constexpr int K_TILE_BYTES = KVB * 256;
+
+struct AttnArgs {
+    const uint16_t* Q; int64_t ldq, bsq;
+    const uint16_t* K; int64_t ldk, bsk;
+    const uint16_t* Vt; int64_t lkp;
+    uint16_t* O; int64_t ldo, bso;
+    int batch, heads, Lq, Lk;
+    float scale_log2;   // softmax scale * log2(e)
+    int accumulate;
+    int nqb;            // q-blocks per (batch, head)
+};
+
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
+    constexpr int KS = HD / 16;          // k-steps of the QK^T contraction
+    constexpr int DB = HD / 32;          // 32-row blocks of O^T
+    constexpr int NCH = HD / 8;          // valid 16-B chunks per K row
+    constexpr int VT_TILE_BYTES = HD * 128;
+    constexpr int STAGE = K_TILE_BYTES + VT_TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 31, hi = lane >> 5;
+
+    // ---- work-group -> (batch*head, q-block): XCD x owns a contiguous range of (bh, qb) items ------------
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
+    const uint16_t* Kp = p.K + (int64_t)b * p.bsk + (int64_t)h * HD;
+    const uint16_t* Vp = p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp;
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
+
+    // ---- Q fragments (B operand): lane (fi,hi) holds Q[q0+fi][16*ks + 8*hi .. +7] -------------------------
+    const int q_row = qb * QB + wave * 32 + fi;
+    bf16x8_t qf[KS];
+    {
+        const int qr = min(q_row, p.Lq - 1);
+        const uint16_t* src = Qp + (int64_t)qr * p.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(src + ks * 16);
+    }
+
+    // ---- staging addresses --------------------------------------------------------------------------------
+    // K tile: 16 pieces of 1 KiB (4 rows x 256 B); wave w issues pieces w and w+8.
+    //   lane -> row = 4*pc + lane/16, physical chunk = lane%16, logical chunk = phys ^ (row&15) (skip if >= NCH)
+    const uint16_t* kg[2];
+    bool kvalid[2];
+    int krow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = wave + 8 * i;
+        const int row = pc * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (row & 15);
+        krow[i] = row;
+        kvalid[i] = chunk < NCH;
+        kg[i] = Kp + chunk * 8;
+    }
+    // Vt tile: HD/8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+8 (if < HD/8).
+    //   lane -> row d = 8*pc + lane/8, physical chunk = lane%8, logical chunk = phys ^ ((d>>1)&7)
+    const uint16_t* vg[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = wave + 8 * i;
+        const int d = pc * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
+        vg[i] = Vp + (int64_t)min(d, HD - 1) * p.lkp + chunk * 8;
+    }
+
+    auto stage = [&](int s, int t) {
+        char* k_lds = smem + s * STAGE;
+        char* v_lds = k_lds + K_TILE_BYTES;
+        const int k0 = t * KVB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pc = wave + 8 * i;
+            if (kvalid[i]) {
+                const int kr = min(k0 + krow[i], p.Lk - 1);
+                FW_GLDS16(kg[i] + (int64_t)kr * p.ldk, k_lds + pc * 1024);
+            }
+            if (pc < HD / 8) FW_GLDS16(vg[i] + k0, v_lds + pc * 1024);
+        }
+    };
+
+    // ---- fragment read offsets ------------------------------------------------------------------------------
+    int kcoff[KS];                    // K: chunk (2ks+hi) ^ (fi&15)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
+    int vcoff[4];                     // Vt: chunk (2s+hi) ^ ((fi>>1)&7)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vcoff[s] = K_TILE_BYTES + fi * 128 + (((2 * s + hi) ^ ((fi >> 1) & 7)) << 4);
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1.0e30f;    // running max of raw scores (finite sentinel: no inf-inf)
+    float l_run = 0.f;         // this half-wave's partial row sum
+    const float c = p.scale_log2;
+
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
+        const char* base = smem + (t & 1) * STAGE;
+
+        // ---- S^T = K Q^T : two 32-key blocks ----------------------------------------------------------------
+        f32x16_t s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8_t k0f = *(const bf16x8_t*)(base + kcoff[ks]);
+            bf16x8_t k1f = *(const bf16x8_t*)(base + 32 * 256 + kcoff[ks]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, qf[ks], s1, 0, 0, 0);
+        }
+        // ---- mask the ragged last tile (keys >= Lk) ----------------------------------------------------------
+        if (t == nt - 1 && (p.Lk & (KVB - 1))) {
+            const int kbase = t * KVB + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kbase + (r & 3) + 8 * (r >> 2);
+                if (kk >= p.Lk) s0[r] = -1.0e30f;
+                if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
+            }
+        }
+        // ---- online softmax (per query = per lane column) ---------------------------------------------------
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c;
+        uint32_t pw[16];   // P^T packed to bf16: words 0..7 from block 0, 8..15 from block 1
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+            const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
+            const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+            const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+            ls += (a0 + a1) + (b0 + b1);
+            pw[r >> 1] = pack_bf16x2(a0, a1);
+            pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
+        }
+        l_run += ls;
+
+        // ---- O^T += Vt P^T : 4 k-steps of 16 keys -------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4_t pv4 = {pw[4 * s], pw[4 * s + 1], pw[4 * s + 2], pw[4 * s + 3]};
+            bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                bf16x8_t vf = *(const bf16x8_t*)(base + d * 32 * 128 + vcoff[s]);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l --------------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Lq) {
+        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * hi;
+                float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
+                float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
+                u32x2_t* ptr = (u32x2_t*)(dst + col);
+                if (p.accumulate) {
+                    const u32x2_t old = *ptr;
+                    v0 += __uint_as_float(old[0] << 16);
+                    v1 += __uint_as_float(old[0] & 0xffff0000u);
+                    v2 += __uint_as_float(old[1] << 16);
+                    v3 += __uint_as_float(old[1] & 0xffff0000u);
+                }
+                u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                *ptr = w;
+            }
+        }
+    }
+}
+
+// V[b][Lk][heads*hd] -> Vt[b][h][d][Lk_pad]; position p inside each 32-key block holds key swap_bits_2_3(p).
+// One work-group transposes a 64-key x 64-channel tile through LDS.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ V, int64_t ldv, int64_t bsv,
+                                                          uint16_t* __restrict__ Vt, int64_t lkp,
+                                                          int heads, int hd, int Lk) {
+    __shared__ uint16_t tile[64][66];
+    const int k0 = blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;            // channel offset inside heads*hd
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int width = heads * hd;
+    // load: 64 keys x 64 channels, 8 channels (16 B) per thread-iteration
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;        // 0..511
+        const int kr = idx >> 3, cc = (idx & 7) * 8;
+        const int key = k0 + kr;
+        u32x4_t v = {0, 0, 0, 0};
+        if (key < Lk && c0 + cc < width) v = *(const u32x4_t*)(V + (int64_t)b * bsv + (int64_t)key * ldv + c0 + cc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[kr][cc + 2 * j] = (uint16_t)(v[j] & 0xffffu);
+            tile[kr][cc + 2 * j + 1] = (uint16_t)(v[j] >> 16);
+        }
+    }
+    __syncthreads();
+    // store: channel row ch, 64 positions; each thread writes 8 consecutive positions (16 B)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;
+        const int ch = idx >> 3, p0 = (idx & 7) * 8;
+        const int chan = c0 + ch;
+        if (chan >= width) continue;
+        const int h = chan / hd, d = chan - h * hd;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pa = p0 + 2 * j, pb = pa + 1;
+            const int ka = (pa & ~12) | ((pa & 4) << 1) | ((pa & 8) >> 1);
+            const int kb = (pb & ~12) | ((pb & 4) << 1) | ((pb & 8) >> 1);
+            w[j] = (uint32_t)tile[ka][ch] | ((uint32_t)tile[kb][ch] << 16);
+        }
+        u32x4_t o4 = {w[0], w[1], w[2], w[3]};
+        *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd + d) * lkp + k0 + p0) = o4;
+    }
+}
+
+}  // namespace
+
+extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
+                                 const uint16_t* K, int64_t ldk, int64_t bsk,
+                                 const uint16_t* Vt, int64_t Lk_pad,
+                                 uint16_t* O, int64_t ldo, int64_t bso,
+                                 int batch, int heads, int head_dim, int Lq, int Lk,
+                                 float scale, int accumulate, void* stream) {
+    if (batch <= 0 || heads <= 0 || Lq <= 0) return 0;
+    if (Lk <= 0) { fw_set_error("fw_attention_bf16: Lk must be > 0"); return FW_E_BADARG; }
+    if (head_dim != 64 && head_dim != 96 && head_dim != 128) { fw_set_error("fw_attention_bf16: head_dim must be 64, 96 or 128"); return FW_E_UNSUPPORTED; }
+    if ((ldq % 8) || (ldk % 8) || (ldo % 4) || (bsq % 8) || (bsk % 8) || (bso % 4) || (Lk_pad % 64) || Lk_pad < Lk ||
+        (((uintptr_t)Q) & 15) || (((uintptr_t)K) & 15) || (((uintptr_t)Vt) & 15) || (((uintptr_t)O) & 7)) {
+        fw_set_error("fw_attention_bf16: alignment contract violated (16-B Q/K/Vt, 8-B O, Lk_pad % 64 == 0)"); return FW_E_BADARG; }
+    AttnArgs p;
+    p.Q = Q; p.ldq = ldq; p.bsq = bsq; p.K = K; p.ldk = ldk; p.bsk = bsk; p.Vt = Vt; p.lkp = Lk_pad;
+    p.O = O; p.ldo = ldo; p.bso = bso; p.batch = batch; p.heads = heads; p.Lq = Lq; p.Lk = Lk;
+    p.scale_log2 = scale * 1.4426950408889634f; p.accumulate = accumulate;
+    p.nqb = (Lq + QB - 1) / QB;
+    const int64_t nwg = (int64_t)p.nqb * heads * batch;
+    if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+    else if (head_dim == 96) hipLaunchKernelGGL(attention_kernel<96>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(attention_kernel<64>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_v_transpose(const uint16_t* V, int64_t ldv, int64_t bsv, uint16_t* Vt, int64_t Lk_pad,
+                              int batch, int heads, int head_dim, int Lk, void* stream) {
+    if (batch <= 0 || heads <= 0 || Lk <= 0) return 0;
+    if ((ldv % 8) || (bsv % 8) || (Lk_pad % 64) || Lk_pad < Lk || (head_dim % 8) || (((uintptr_t)V) & 15) || (((uintptr_t)Vt) & 15)) {
+        fw_set_error("fw_v_transpose: alignment contract violated"); return FW_E_BADARG; }
+    const int width = heads * head_dim;
+    dim3 grid((unsigned)(Lk_pad / 64), (unsigned)((width + 63) / 64), (unsigned)batch);
+    hipLaunchKernelGGL(v_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, ldv, bsv, Vt, Lk_pad, heads, head_dim, Lk);
+    return (int)hipGetLastError();
+}

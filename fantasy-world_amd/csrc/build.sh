@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds libfw_mi355x.so (gfx950 only) next to the package.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../libfw_mi355x.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result)
+objs=()
+for f in gemm.hip attention.hip elementwise.hip; do
+  o="${here}/${f%.hip}.o"
+  if [ ! -f "$o" ] || [ "${here}/$f" -nt "$o" ] || [ "${here}/fw_common.h" -nt "$o" ] || [ "${here}/../../include/fw_mi355x.h" -nt "$o" ]; then
+    "$HIPCC" "${flags[@]}" -c "${here}/$f" -o "$o" &
+  fi
+  objs+=("$o")
+done
+o="${here}/api.o"
+"$HIPCC" "${flags[@]}" -x hip -c "${here}/api.cpp" -o "$o" &
+objs+=("$o")
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+echo "built $out"

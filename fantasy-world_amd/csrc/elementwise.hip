@@ -1,0 +1,366 @@
+// HBM-bound glue kernels of the denoising forward (gfx950): LayerNorm+modulate, q/k norm + rotary, sinusoidal
+// embedding, patchify / unpatchify, VGGT token assembly, fp32->bf16 cast.  All loads/stores are 8-16 B per lane.
+#include "fw_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm (+affine) (+ (1+scale)*y + shift), one 256-thread work-group per row, row kept in registers.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;   // float4 per thread -> C <= 8192
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool XF32>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const void* __restrict__ xin, int64_t ldx,
+                                                            uint16_t* __restrict__ y, int64_t ldy, int C,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int nv = C >> 2;
+    f32x4_t v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < nv) {
+            if (XF32) {
+                v[i] = *(const f32x4_t*)((const float*)xin + (int64_t)row * ldx + idx * 4);
+            } else {
+                const u32x2_t raw = *(const u32x2_t*)((const uint16_t*)xin + (int64_t)row * ldx + idx * 4);
+                v[i][0] = __uint_as_float(raw[0] << 16); v[i][1] = __uint_as_float(raw[0] & 0xffff0000u);
+                v[i][2] = __uint_as_float(raw[1] << 16); v[i][3] = __uint_as_float(raw[1] & 0xffff0000u);
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = block_sum_256(s, red) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(block_sum_256(q, red) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < nv) {
+            const int c0 = idx * 4;
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = (v[i][j] - mean) * rstd;
+                if (w) t = t * w[c0 + j] + (b ? b[c0 + j] : 0.f);
+                if (scale) t = t * (1.0f + scale[c0 + j]);
+                if (shift) t += shift[c0 + j];
+                o[j] = t;
+            }
+            u32x2_t out = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *(u32x2_t*)(y + (int64_t)row * ldy + c0) = out;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// q/k normalisation + rotary, in place on a bf16 [rows][heads*hd] slice.  One work-group per row; each thread
+// owns up to QK_MAXC chunks of 8 consecutive channels; the normalised row is parked in LDS (fp32) so the rotary
+// partner (i^1 for interleaved pairs, i +- hd/4 for the 2-D rotate-half form) can be fetched by any thread.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int QK_MAXC = 3;     // width <= 3 * 256 * 8 = 6144
+constexpr int QK_MAXW = 6144;
+
+__global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, int64_t ldx, int heads, int hd,
+                                                      int norm_mode, const float* __restrict__ nw, const float* __restrict__ nb,
+                                                      float eps, int rope_mode, const float* __restrict__ tab, int tab_rows) {
+    __shared__ float rowbuf[QK_MAXW];
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const int width = heads * hd;
+    const int nch = width >> 3;
+    uint16_t* xr = x + (int64_t)row * ldx;
+    float v[QK_MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < QK_MAXC; ++i) {
+        const int ch = threadIdx.x + i * 256;
+        if (ch < nch) {
+            const u32x4_t raw = *(const u32x4_t*)(xr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[i][2 * j] = __uint_as_float(raw[j] << 16);
+                v[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+        }
+    }
+    if (norm_mode == FW_NORM_RMS_FULL) {
+        const float tot = block_sum_256(ss, red);
+        const float r = rsqrtf(tot / (float)width + eps);
+#pragma unroll
+        for (int i = 0; i < QK_MAXC; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = v[i][j] * r * nw[ch * 8 + j];
+            }
+        }
+    } else if (norm_mode == FW_NORM_LN_HEAD) {
+        // head_dim == 64: a head is 8 consecutive chunks = 8 consecutive lanes (chunk index = tid + 256 i)
+#pragma unroll
+        for (int i = 0; i < QK_MAXC; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            float s1 = 0.f;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s1 += v[i][j];
+            }
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+            const float mean = s1 * (1.0f / 64.0f);
+            float s2 = 0.f;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
+            }
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+            const float r = rsqrtf(s2 * (1.0f / 64.0f) + eps);
+            if (ch < nch) {
+                const int d0 = (ch * 8) & 63;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * r * nw[d0 + j] + nb[d0 + j];
+            }
+        }
+    }
+    if (rope_mode == FW_ROPE_NONE) {
+#pragma unroll
+        for (int i = 0; i < QK_MAXC; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nch) {
+                u32x4_t o = {pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]),
+                             pack_bf16x2(v[i][4], v[i][5]), pack_bf16x2(v[i][6], v[i][7])};
+                *(u32x4_t*)(xr + ch * 8) = o;
+            }
+        }
+        return;
+    }
+    const float* trow = tab + (int64_t)(row % tab_rows) * hd;   // [hd/2][2]
+    if (rope_mode == FW_ROPE_INTERLEAVED) {
+        // partner is inside the same chunk
+#pragma unroll
+        for (int i = 0; i < QK_MAXC; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < nch) {
+                const int e0 = (ch * 8) % hd;      // element offset inside the head
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float cs = trow[(e0 / 2 + j) * 2], sn = trow[(e0 / 2 + j) * 2 + 1];
+                    const float a = v[i][2 * j], bq = v[i][2 * j + 1];
+                    o[j] = pack_bf16x2(a * cs - bq * sn, a * sn + bq * cs);
+                }
+                u32x4_t o4 = {o[0], o[1], o[2], o[3]};
+                *(u32x4_t*)(xr + ch * 8) = o4;
+            }
+        }
+        return;
+    }
+    // FW_ROPE_HALF2D: head = [y half | x half], each half hd/2 wide, rotate-half pairs (w, w + hd/4)
+#pragma unroll
+    for (int i = 0; i < QK_MAXC; ++i) {
+        const int ch = threadIdx.x + i * 256;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rowbuf[ch * 8 + j] = v[i][j];
+        }
+    }
+    __syncthreads();
+    const int half = hd >> 1, quarter = hd >> 2;
+#pragma unroll
+    for (int i = 0; i < QK_MAXC; ++i) {
+        const int ch = threadIdx.x + i * 256;
+        if (ch < nch) {
+            const int base = ch * 8;
+            const int e0 = base % hd;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = e0 + j;
+                const int hsel = e / half, wi = e - hsel * half;
+                const bool lo = wi < quarter;
+                const int pidx = hsel * quarter + (lo ? wi : wi - quarter);
+                const float cs = trow[pidx * 2], sn = trow[pidx * 2 + 1];
+                const float partner = rowbuf[base + j + (lo ? quarter : -quarter)];
+                o[j] = lo ? (v[i][j] * cs - partner * sn) : (v[i][j] * cs + partner * sn);
+            }
+            u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+            *(u32x4_t*)(xr + base) = o4;
+        }
+    }
+}
+
+__global__ void sinusoid_kernel(const void* __restrict__ t, int t_dtype, float* __restrict__ out, int dim) {
+    const int half = dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    double pos;
+    if (t_dtype == FW_DT_BF16) pos = (double)bf16_bits_to_f32(*(const uint16_t*)t);
+    else pos = (double)(*(const float*)t);
+    const double f = pow(10000.0, -((double)i / (double)half));
+    const double a = pos * f;
+    out[i] = (float)cos(a);
+    out[half + i] = (float)sin(a);
+}
+
+__device__ __forceinline__ float load_any(const void* p, int64_t i, int dtype) {
+    return dtype == FW_DT_BF16 ? bf16_bits_to_f32(((const uint16_t*)p)[i]) : ((const float*)p)[i];
+}
+
+// one thread per (token l, channel c'): writes 4 bf16 (c'*4 .. c'*4+3); c' >= Cx+Cy writes the zero pad
+__global__ __launch_bounds__(256) void patchify_kernel(const void* __restrict__ x, int Cx, const void* __restrict__ y, int Cy, int dtype,
+                                                       uint16_t* __restrict__ P, int64_t ldp, int F, int H2, int W2, int cols4) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Hh = H2 >> 1, Ww = W2 >> 1;
+    const int64_t L = (int64_t)F * Hh * Ww;
+    if (gid >= L * cols4) return;
+    const int c = (int)(gid % cols4);
+    const int64_t l = gid / cols4;
+    const int w = (int)(l % Ww), h = (int)((l / Ww) % Hh), f = (int)(l / ((int64_t)Ww * Hh));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < Cx + Cy) {
+        const void* src = c < Cx ? x : y;
+        const int cc = c < Cx ? c : c - Cx;
+        const int64_t base = (((int64_t)cc * F + f) * H2 + 2 * h) * W2 + 2 * w;
+        v[0] = load_any(src, base, dtype); v[1] = load_any(src, base + 1, dtype);
+        v[2] = load_any(src, base + W2, dtype); v[3] = load_any(src, base + W2 + 1, dtype);
+    }
+    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2_t*)(P + l * ldp + c * 4) = o;
+}
+
+// one thread per (token l, column): column = (y*2+z)*16 + c  (patch (1,2,2), 16 output channels)
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ Hd, int64_t ldh, void* __restrict__ out, int out_dtype,
+                                                         int F, int Hh, int Ww) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t L = (int64_t)F * Hh * Ww;
+    if (gid >= L * 64) return;
+    const int col = (int)(gid & 63);
+    const int64_t l = gid >> 6;
+    const int w = (int)(l % Ww), h = (int)((l / Ww) % Hh), f = (int)(l / ((int64_t)Ww * Hh));
+    const int c = col & 15, z = (col >> 4) & 1, yy = (col >> 5) & 1;
+    const float v = Hd[l * ldh + col];
+    const int64_t o = (((int64_t)c * F + f) * (2 * Hh) + 2 * h + yy) * (2 * Ww) + 2 * w + z;
+    if (out_dtype == FW_DT_F32) ((float*)out)[o] = v;
+    else ((uint16_t*)out)[o] = f32_to_bf16_bits(v);
+}
+
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const uint16_t* __restrict__ patch, int64_t ldp,
+                                                              const float* __restrict__ special, float* __restrict__ tokens,
+                                                              int S, int hw, int n_special, int C) {
+    const int P = n_special + hw;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 4 channels
+    const int c4 = C >> 2;
+    if (gid >= (int64_t)S * P * c4) return;
+    const int cc = (int)(gid % c4) * 4;
+    const int64_t tp = gid / c4;
+    const int pidx = (int)(tp % P);
+    const int s = (int)(tp / P);
+    f32x4_t v;
+    if (pidx < n_special) {
+        v = *(const f32x4_t*)(special + ((int64_t)(s == 0 ? 0 : 1) * n_special + pidx) * C + cc);
+    } else {
+        const u32x2_t raw = *(const u32x2_t*)(patch + ((int64_t)s * hw + (pidx - n_special)) * ldp + cc);
+        v[0] = __uint_as_float(raw[0] << 16); v[1] = __uint_as_float(raw[0] & 0xffff0000u);
+        v[2] = __uint_as_float(raw[1] << 16); v[3] = __uint_as_float(raw[1] & 0xffff0000u);
+    }
+    *(f32x4_t*)(tokens + tp * C + cc) = v;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y, int64_t ldy,
+                                                            int rows, int C) {
+    const int c4 = C >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)rows * c4) return;
+    const int cc = (int)(gid % c4) * 4;
+    const int64_t r = gid / c4;
+    const f32x4_t v = *(const f32x4_t*)(x + r * ldx + cc);
+    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    *(u32x2_t*)(y + r * ldy + cc) = o;
+}
+
+}  // namespace
+
+extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_t* y, int64_t ldy, int rows, int C,
+                                const float* w, const float* b, const float* scale, const float* shift, float eps, void* stream) {
+    if (rows <= 0) return 0;
+    if (C <= 0 || (C % 4) || C > LN_MAXV * 256 * 4 || (ldx % 4) || (ldy % 4)) { fw_set_error("fw_layernorm_mod: C % 4 == 0, C <= 8192, ld % 4 == 0 required"); return FW_E_BADARG; }
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == FW_DT_F32) hipLaunchKernelGGL(layernorm_mod_kernel<true>, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, C, w, b, scale, shift, eps);
+    else if (x_dtype == FW_DT_BF16) hipLaunchKernelGGL(layernorm_mod_kernel<false>, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, C, w, b, scale, shift, eps);
+    else { fw_set_error("fw_layernorm_mod: bad x_dtype"); return FW_E_BADARG; }
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
+                          const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, void* stream) {
+    if (rows <= 0) return 0;
+    const int width = heads * head_dim;
+    if (width > QK_MAXW || (head_dim % 8) || (ldx % 8) || (((uintptr_t)x) & 15)) { fw_set_error("fw_qk_prep: width <= 6144, head_dim % 8 == 0, 16-B alignment required"); return FW_E_BADARG; }
+    if (norm_mode == FW_NORM_LN_HEAD && (head_dim != 64 || !norm_w || !norm_b)) { fw_set_error("fw_qk_prep: LN_HEAD needs head_dim 64 and weight+bias"); return FW_E_BADARG; }
+    if (norm_mode == FW_NORM_RMS_FULL && !norm_w) { fw_set_error("fw_qk_prep: RMS_FULL needs a weight"); return FW_E_BADARG; }
+    if (rope_mode != FW_ROPE_NONE && (!rope_tab || tab_rows <= 0)) { fw_set_error("fw_qk_prep: rope table missing"); return FW_E_BADARG; }
+    if (rope_mode == FW_ROPE_HALF2D && (head_dim % 32)) { fw_set_error("fw_qk_prep: HALF2D needs head_dim % 32 == 0"); return FW_E_BADARG; }
+    hipLaunchKernelGGL(qk_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, heads, head_dim, norm_mode,
+                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_sinusoid(const void* t, int t_dtype, float* out, int dim, void* stream) {
+    if (dim <= 0 || (dim & 1) || (t_dtype != FW_DT_BF16 && t_dtype != FW_DT_F32)) { fw_set_error("fw_sinusoid: bad args"); return FW_E_BADARG; }
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((dim / 2 + 63) / 64), dim3(64), 0, (hipStream_t)stream, t, t_dtype, out, dim);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_patchify(const void* x, int Cx, const void* y, int Cy, int dtype, uint16_t* P, int64_t ldp,
+                           int F, int H2, int W2, void* stream) {
+    if ((H2 & 1) || (W2 & 1) || (ldp % 4) || ldp < 4 * (Cx + Cy) || (dtype != FW_DT_BF16 && dtype != FW_DT_F32)) { fw_set_error("fw_patchify: bad args"); return FW_E_BADARG; }
+    const int cols4 = (int)(ldp / 4);
+    const int64_t n = (int64_t)F * (H2 / 2) * (W2 / 2) * cols4;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, Cx, y, Cy, dtype, P, ldp, F, H2, W2, cols4);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_unpatchify(const float* Hd, int64_t ldh, void* out, int out_dtype, int F, int Hh, int Ww, void* stream) {
+    if (out_dtype != FW_DT_BF16 && out_dtype != FW_DT_F32) { fw_set_error("fw_unpatchify: bad out_dtype"); return FW_E_BADARG; }
+    const int64_t n = (int64_t)F * Hh * Ww * 64;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Hd, ldh, out, out_dtype, F, Hh, Ww);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_assemble_tokens(const uint16_t* patch, int64_t ldp, const float* special, float* tokens,
+                                  int S, int hw, int n_special, int C, void* stream) {
+    if ((C % 4) || (ldp % 4)) { fw_set_error("fw_assemble_tokens: C % 4 == 0 required"); return FW_E_BADARG; }
+    const int64_t n = (int64_t)S * (n_special + hw) * (C / 4);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, patch, ldp, special, tokens, S, hw, n_special, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C, void* stream) {
+    if ((C % 4) || (ldx % 4) || (ldy % 4)) { fw_set_error("fw_cast_f32_bf16: C % 4 == 0 required"); return FW_E_BADARG; }
+    const int64_t n = (int64_t)rows * (C / 4);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,58 @@
+// Shared device helpers for the gfx950 kernels of libfw_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fw_mi355x.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define FW_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define FW_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-byte async global->LDS copy: LDS destination = wave-uniform base + lane*16 (gfx950 global_load_lds_dwordx4)
+#define FW_GLDS16(gptr, ldsbase) __builtin_amdgcn_global_load_lds(FW_GLB_PTR(gptr), FW_LDS_PTR(ldsbase), 16, 0, 0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 bits (NaN preserved as quiet NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ float fw_gelu_tanh(float x) {
+    // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))  == x * sigmoid(2u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}
+__device__ __forceinline__ float fw_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float fw_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float fw_apply_act(float v, int act) {
+    switch (act) {
+        case FW_ACT_RELU: return v > 0.f ? v : 0.f;
+        case FW_ACT_GELU_TANH: return fw_gelu_tanh(v);
+        case FW_ACT_GELU_ERF: return fw_gelu_erf(v);
+        case FW_ACT_SILU: return fw_silu(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// host-side error plumbing (api.cpp)
+void fw_set_error(const char* msg);

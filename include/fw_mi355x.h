@@ -1,0 +1,170 @@
+/*
+ * fw_mi355x.h -- C ABI of libfw_mi355x.so: the MI355X (gfx950 / CDNA4) kernels behind
+ * FantasyWorld's per-step denoising forward (FantasyWorldFusionModel.joint_forward).
+ *
+ * The reference (Fantasy-AMAP/fantasy-world) has no FFI: every hot op is a call into PyTorch
+ * (SURVEY.md 2.3).  Each entry point below replaces one family of those call sites; the file:line
+ * next to it is the reference code whose arithmetic it implements (paths relative to the reference
+ * repo root; DIT21 = FantasyWorld/diffsynth_wan21/models/wan_video_dit.py, IRG =
+ * FantasyWorld/fusion/layer/block.py, VB/VA/VR = FantasyWorld/vggt/layers/{block,attention,rope}.py,
+ * CAM = FantasyWorld/diffsynth_wan21/models/camera_control.py, M21 = FantasyWorld/fusion/model_wan21.py).
+ *
+ * Conventions:
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch); the library never allocates,
+ *     frees or synchronises; every call only enqueues work on `stream` (a hipStream_t passed as void*).
+ *   - bf16 = raw IEEE bfloat16 bits (uint16_t); "ld*" arguments are leading dimensions in ELEMENTS.
+ *   - every function returns 0 on success, a positive hipError_t, or a negative FW_E_* code.
+ *   - no C++ types, no torch types, no exceptions cross this boundary.
+ */
+#ifndef FW_MI355X_H
+#define FW_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FW_ABI_VERSION 1
+
+/* error codes (negative; positive values are hipError_t) */
+#define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
+#define FW_E_UNSUPPORTED (-2)
+
+/* dtype enums for residual / output tensors */
+#define FW_DT_NONE 0
+#define FW_DT_BF16 1
+#define FW_DT_F32  2
+
+/* activation applied to (acc + bias) in fw_gemm_bf16 / fw_gemv_f32 */
+#define FW_ACT_NONE      0
+#define FW_ACT_RELU      1   /* CAM:29-33,47-49 (adapter MLPs) */
+#define FW_ACT_GELU_TANH 2   /* DIT21:274-275 FFN, DIT21:388-392 text_embedding */
+#define FW_ACT_GELU_ERF  3   /* DIT21:330 img_emb, vggt/layers/mlp.py:22 */
+#define FW_ACT_SILU      4   /* DIT21:393-399 time_embedding / time_projection */
+
+/* q/k normalisation modes of fw_qk_prep */
+#define FW_NORM_NONE      0  /* IRG:547-551 (bicross q,k: no norm) */
+#define FW_NORM_RMS_FULL  1  /* DIT21:135-146,170-171: RMSNorm over the FULL width (all heads), weight[width] */
+#define FW_NORM_LN_HEAD   2  /* VA:43-44,55: LayerNorm(head_dim) per head, affine weight/bias[head_dim] */
+
+/* rotary modes of fw_qk_prep */
+#define FW_ROPE_NONE        0
+#define FW_ROPE_INTERLEAVED 1 /* DIT21:97-102: complex multiply on pairs (2i,2i+1) */
+#define FW_ROPE_HALF2D      2 /* VR:120-131,154-188: two hd/2 halves (y,x), rotate-half pairs (i,i+hd/4) */
+
+int fw_abi_version(void);
+
+/* Human-readable description of the last negative error on this thread (never NULL). */
+const char* fw_last_error(void);
+
+/*
+ * C[M,N] = epilogue( A[M,K] @ W[N,K]^T )   -- every nn.Linear on the hot path
+ * (DIT21:166-169,216-225,274-275,357,388-392; IRG:340-346; VA:42,46; mlp.py:29-31; CAM:27-51;
+ *  VGGT.projection_head = 1x1x1 Conv3d = Linear, vggt/models/vggt.py:32; patch_embedding Conv3d
+ *  k=s=(1,2,2) = Linear over gathered 144-wide patches, DIT21:386,424-435).
+ *   y = acc + bias[n]                      (bias may be NULL)
+ *   y = act(y)
+ *   y = y * g1[n] + g0[n]                  (g1/g0 may be NULL -> 1 / 0): gates, LayerScale, VGGT post-MLP modulation
+ *   y = y + res[m,n]                       (res_dtype FW_DT_NONE / BF16 / F32; ldr leading dim)
+ *   C = (out_dtype) y                      (FW_DT_BF16 or FW_DT_F32; C may alias res)
+ * A, W: bf16 row-major, K % 64 == 0 (callers zero-pad), lda/ldw % 8 == 0, 16-byte aligned bases.
+ * bf16 MFMA 32x32x16, fp32 accumulate.
+ */
+int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
+                 void* C, int64_t ldc, int out_dtype,
+                 int M, int N, int K,
+                 const float* bias, int act, const float* g1, const float* g0,
+                 const void* res, int64_t ldr, int res_dtype,
+                 void* stream);
+
+/*
+ * Non-causal softmax(Q K^T * scale) V for head_dim in {64, 96, 128}
+ * (DIT21:28-66 flash_attention; IRG:598-605 the two bidirectional SDPA calls; VA:61).
+ *   Q : [batch][Lq][heads*hd] bf16, row stride ldq, batch stride bsq (elements); same for K (ldk, bsk).
+ *   Vt: [batch][heads][hd][Lk_pad] bf16, produced by fw_v_transpose (keys permuted inside each 32-block,
+ *       zero padded to Lk_pad = roundup(Lk, 64)).
+ *   O : [batch][Lq][heads*hd] bf16 (ldo, bso).  accumulate != 0 -> O += result (cross-attn text+image sum,
+ *       DIT21:197-200).
+ * fp32 online softmax, bf16 MFMA 32x32x16 for QK^T and PV.
+ */
+int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
+                      const uint16_t* K, int64_t ldk, int64_t bsk,
+                      const uint16_t* Vt, int64_t Lk_pad,
+                      uint16_t* O, int64_t ldo, int64_t bso,
+                      int batch, int heads, int head_dim, int Lq, int Lk,
+                      float scale, int accumulate, void* stream);
+
+/*
+ * V[batch][Lk][heads*hd] (ldv, bsv) -> Vt[batch][heads][hd][Lk_pad] in the key order fw_attention_bf16 expects.
+ */
+int fw_v_transpose(const uint16_t* V, int64_t ldv, int64_t bsv, uint16_t* Vt, int64_t Lk_pad,
+                   int batch, int heads, int head_dim, int Lk, void* stream);
+
+/*
+ * LayerNorm over the last dim + optional affine + optional AdaLN modulation, bf16 out
+ * (DIT21:267-273,301,305,310 norm1/2/3 + modulate; DIT21:350-357 Head; IRG:164-167,199 bicross norms;
+ *  VB:45,63,73-81 norm1/norm2; DIT21:324-341 img_emb LayerNorms).
+ *   y = (x - mean) * rsqrt(var + eps); y = y*w + b (w,b may be NULL); y = y*(1+scale) + shift (may be NULL)
+ * x: [rows][C] f32 or bf16 (x_dtype), ldx; y: bf16 [rows][C], ldy. C % 8 == 0, C <= 8192.
+ */
+int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_t* y, int64_t ldy,
+                     int rows, int C, const float* w, const float* b,
+                     const float* scale, const float* shift, float eps, void* stream);
+
+/*
+ * In-place q/k post-projection: normalisation + rotary embedding on a [rows][heads*hd] bf16 slice (ldx).
+ *   norm_mode: FW_NORM_*; norm_w (and norm_b for LN_HEAD) fp32.
+ *   rope_mode: FW_ROPE_*; rope_tab = fp32 [tab_rows][hd/2][2] (cos,sin), row used = row % tab_rows
+ *   (DIT21:97-102,170-182 RMSNorm+RoPE3D; VA:55-59 + VR:154-188; IRG:547-551 with the identity rows of
+ *    DIT21:105-132 baked into the table).
+ */
+int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim,
+               int norm_mode, const float* norm_w, const float* norm_b, float eps,
+               int rope_mode, const float* rope_tab, int tab_rows, void* stream);
+
+/*
+ * out[n] = act( sum_k x[k]*W[n,k] + bias[n] ), all fp32, M = 1 (time embeddings:
+ * DIT21:393-399, M21:119-121, vggt/models/vggt.py:126-130 fp32 island).
+ */
+int fw_gemv_f32(const float* x, const float* W, int64_t ldw, const float* bias, float* out,
+                int N, int K, int act_in_silu, int act_out, void* stream);
+
+/*
+ * out[0:dim/2] = cos(t * 10000^(-i/(dim/2))), out[dim/2:] = sin(...), computed in fp64 then cast to fp32
+ * (DIT21:73-77, wan/modules/model.py:17-27).  t is read from device memory as t_dtype (bf16 or f32).
+ */
+int fw_sinusoid(const void* t, int t_dtype, float* out, int dim, void* stream);
+
+/*
+ * Patchify gather: latents x[Cx][F][H2][W2] and y[Cy][F][H2][W2] (bf16 or f32, dtype) ->
+ * P[L][Kpad] bf16 with L = F*(H2/2)*(W2/2), column (c*4 + dy*2 + dx) = in[c][f][2h+dy][2w+dx], zero pad
+ * to Kpad (Conv3d k=s=(1,2,2) as a GEMM, DIT21:386,424-435; channel concat M21:125-126).
+ */
+int fw_patchify(const void* x, int Cx, const void* y, int Cy, int dtype,
+                uint16_t* P, int64_t ldp, int F, int H2, int W2, void* stream);
+
+/*
+ * Unpatchify scatter: head output Hd[L][64] (f32) -> out[16][F][2h][2w] (out_dtype), channel order
+ * (x y z c) of DIT21:437-442.
+ */
+int fw_unpatchify(const float* Hd, int64_t ldh, void* out, int out_dtype, int F, int Hh, int Ww, void* stream);
+
+/*
+ * VGGT token assembly (vggt/models/aggregator.py:261-306): tokens[S][P][C] f32 with P = n_special + hw:
+ * rows [0,n_special) <- special[(s==0?0:1)][n_special][C] (camera token then register tokens),
+ * rows [n_special, P) <- patch[s*hw + i][C] (bf16, ldp).
+ */
+int fw_assemble_tokens(const uint16_t* patch, int64_t ldp, const float* special, float* tokens,
+                       int S, int hw, int n_special, int C, void* stream);
+
+/*
+ * y[rows][C] (bf16) = x[rows][C] (f32): the DiT->VGGT bridge feeds the raw residual stream to
+ * projection_head (M21:170-173, vggt/models/vggt.py:123).
+ */
+int fw_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FW_MI355X_H */

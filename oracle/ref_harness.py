@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE ONLY -- harness that imports the *real* reference from /root/reference.
+
+Used in the build container (where /root/reference is mounted) to
+  (1) pin oracle/fw_oracle.py (the CPU restatement) against the reference's own modules, and
+  (2) generate the golden fixtures under tests/golden/ (see oracle/make_golden.py).
+It cannot travel to the GPU box (no /root/reference there); nothing in the product path
+(fantasy-world_amd/) may import it.
+
+What it does:
+  * registers permissive stub modules for the non-hot-path imports the container lacks
+    (diffusers, modelscope, torchvision, imageio, cv2, ftfy, easydict, ...), leaving
+    flash_attn / sageattention / xformers genuinely absent so the reference takes its SDPA branch
+    (FantasyWorld/diffsynth_wan21/models/wan_video_dit.py:28-66);
+  * builds FantasyWorldFusionModel WITHOUT checkpoints via __new__ + nn.Module.__init__, repeating the
+    IRG-assembly loop of FantasyWorld/fusion/model_wan21.py:69-87;
+  * loads deterministic synthetic weights (fantasy_world_amd.synth) by parameter name.
+"""
+import copy
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REFERENCE_ROOT = os.environ.get("FW_REFERENCE_ROOT", "/root/reference")
+
+_STUB_TOPLEVEL = {
+    "diffusers", "modelscope", "torchvision", "imageio", "cv2", "ftfy", "easydict", "decord", "av",
+    "controlnet_aux", "sentencepiece_stub", "xfuser", "apex", "moviepy", "matplotlib", "trimesh",
+    "open3d", "lpips", "kornia", "timm", "peft", "librosa", "soundfile", "dashscope", "gradio",
+}
+
+
+class _Anything:
+    """Callable/class stand-in: usable as base class, decorator, or attribute bag."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]          # behaves as an identity decorator (e.g. register_to_config)
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+class _StubModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (_Anything,), {})
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in _STUB_TOPLEVEL:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+_installed = False
+
+
+def install_stubs():
+    global _installed
+    if _installed:
+        return
+    sys.dont_write_bytecode = True           # reference tree is read-only
+    if not os.path.isdir(REFERENCE_ROOT):
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT} (expected: the build container)")
+    for name in list(_STUB_TOPLEVEL):
+        try:
+            importlib.import_module(name)
+            _STUB_TOPLEVEL.discard(name)     # really installed: do not shadow it
+        except Exception:
+            pass
+    sys.meta_path.append(_StubFinder())
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    _installed = True
+
+
+class _FakePipe(nn.Module):
+    """The slice of WanVideoPipeline that joint_forward/generate_video touch (M21:104-322)."""
+
+    def __init__(self, dit, scheduler):
+        super().__init__()
+        self.dit = dit
+        self.scheduler = scheduler
+        self.torch_dtype = torch.float32
+        self.device = "cpu"
+
+    def generate_noise(self, shape, seed=None, device="cpu", dtype=torch.float32):
+        g = None if seed is None else torch.Generator(device="cpu").manual_seed(seed)
+        return torch.randn(shape, generator=g, dtype=dtype)
+
+    def prepare_extra_input(self, latents=None):
+        return {}
+
+    def load_models_to_device(self, names):
+        pass
+
+
+def build_reference_wan21(cfg, weights=None):
+    """Build the reference FantasyWorldFusionModel (Wan2.1 flavour) for `cfg` (fantasy_world_amd.config.FWConfig).
+
+    Mirrors FantasyWorld/fusion/model_wan21.py:24-102 without touching checkpoints or "cuda".
+    """
+    install_stubs()
+    from FantasyWorld.fusion.model_wan21 import FantasyWorldFusionModel
+    from FantasyWorld.fusion.layer.block import IRGBlock
+    from FantasyWorld.diffsynth_wan21.models.wan_video_dit import WanModel, precompute_freqs_cis_3d
+    from FantasyWorld.diffsynth_wan21.models.camera_control import CameraConditionModel
+    from FantasyWorld.diffsynth_wan21.schedulers.flow_match import FlowMatchScheduler
+    from FantasyWorld.vggt.models.vggt import VGGT
+
+    torch.manual_seed(0)
+    model = FantasyWorldFusionModel.__new__(FantasyWorldFusionModel)
+    nn.Module.__init__(model)
+    with torch.device("meta") if weights is not None else _nullctx():
+        dit = WanModel(dim=cfg.dim, in_dim=cfg.in_dim, ffn_dim=cfg.ffn_dim, out_dim=cfg.out_dim,
+                       text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, eps=cfg.eps, patch_size=(1, 2, 2),
+                       num_heads=cfg.num_heads, num_layers=cfg.num_layers, has_image_input=cfg.has_image_input)
+        vggt = VGGT(enable_camera=True, enable_depth=True, enable_point=True, enable_track=False,
+                    DPT_patch_size=16)
+    if weights is not None:
+        # RoPE tables are plain attributes (not buffers): rebuild them off the meta device
+        dit.freqs = precompute_freqs_cis_3d(cfg.dim // cfg.num_heads)
+    sched = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
+    model.pipe = _FakePipe(dit, sched)
+    model.vggt = vggt
+    # keep only the VGGT blocks the reduced-depth model uses
+    n_irg = cfg.num_layers - cfg.start_index
+    vggt.aggregator.frame_blocks = nn.ModuleList(list(vggt.aggregator.frame_blocks)[:n_irg])
+    vggt.aggregator.global_blocks = nn.ModuleList(list(vggt.aggregator.global_blocks)[:n_irg])
+    model.camera_control = cfg.camera_adapter
+    if cfg.camera_adapter:
+        with torch.device("meta") if weights is not None else _nullctx():
+            model.camera_condition = CameraConditionModel(dit, 768, cfg.plucker_dim, "adaln", "plucker")
+    model.start_index = cfg.start_index
+    model.use_gradient_checkpointing = False
+    model.use_gradient_checkpointing_offload = False
+    model.cross_attention_list = list(cfg.cross_attention_list)
+    model.device = "cpu"
+    model.bicross_dim = cfg.bicross_dim
+    model.bicross_num_heads = cfg.bicross_heads
+    model.freqs_bicross = precompute_freqs_cis_3d(cfg.bicross_dim // cfg.bicross_heads)
+    irg_blocks = nn.ModuleList()
+    for idx in model.cross_attention_list:
+        src_dit_blk = dit.blocks[idx + model.start_index]
+        src_agg_blk = vggt.aggregator.global_blocks[idx]
+        dit_blk_copy = copy.deepcopy(src_dit_blk)
+        agg_blk_copy = copy.deepcopy(src_agg_blk)
+        dit.blocks[idx + model.start_index] = nn.Identity()
+        vggt.aggregator.global_blocks[idx] = nn.Identity()
+        with torch.device("meta") if weights is not None else _nullctx():
+            irg_blocks.append(IRGBlock(x_agg_block=agg_blk_copy, x_dit_block=dit_blk_copy,
+                                       m1_dim=dit.dim, m2_dim=vggt.embed_dim, hidden_size=model.bicross_dim,
+                                       num_heads=model.bicross_num_heads, drop_path=None))
+    model.IRGBlock = irg_blocks
+    model.use_info = "plucker"
+    model.drop_ratio = 0.17
+    if weights is not None:
+        load_named_weights(model, weights)
+    model.eval()
+    return model
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def reference_param_names(model, hot_only=True):
+    """Names (relative to the fusion model) of every parameter, optionally dropping the non-hot-path ones."""
+    names = []
+    for k, _ in model.named_parameters():
+        names.append(k)
+    return names
+
+
+def load_named_weights(model, weights):
+    """Assign tensors from `weights` (name -> tensor) onto the (possibly meta) reference module tree.
+
+    Parameters that are not on the per-step hot path (geometry heads, pose encoder, CamTokenProjector)
+    and are absent from `weights` are materialised as zeros so that the module tree is usable.
+    """
+    missing = []
+    used = set()
+    for name, p in list(model.named_parameters()):
+        mod, leaf = _resolve(model, name)
+        if name in weights:
+            t = weights[name].detach().to(torch.float32).clone()
+            assert tuple(t.shape) == tuple(p.shape), (name, tuple(t.shape), tuple(p.shape))
+            used.add(name)
+        else:
+            missing.append(name)
+            t = torch.zeros(p.shape, dtype=torch.float32)
+        mod._parameters[leaf] = nn.Parameter(t, requires_grad=False)
+    for name, b in list(model.named_buffers()):
+        if b.is_meta:
+            mod, leaf = _resolve(model, name)
+            mod._buffers[leaf] = torch.zeros(b.shape, dtype=b.dtype)
+    unused = sorted(set(weights) - used)
+    model._fw_missing = missing
+    model._fw_unused = unused
+    return missing, unused
+
+
+def _resolve(model, dotted):
+    parts = dotted.split(".")
+    mod = model
+    for p in parts[:-1]:
+        mod = getattr(mod, p)
+    return mod, parts[-1]
