@@ -1,0 +1,8 @@
+"""fantasy-world_amd: MI355X-native (gfx950) execution of FantasyWorld's per-step denoising forward.
+
+The directory name carries a hyphen (it mirrors the reference repo's name); import it as `fantasy_world_amd`
+(the tiny shim package of that name at the repo root redirects here).
+"""
+from .config import FWConfig, wan21_14b, plumbing  # noqa: F401
+
+__all__ = ["FWConfig", "wan21_14b", "plumbing"]

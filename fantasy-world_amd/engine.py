@@ -1,0 +1,406 @@
+"""MI355X-native execution of FantasyWorldFusionModel.joint_forward (Wan2.1 flavour).
+
+Host-side orchestration only: every arithmetic op is a call on `ops` (fantasy_world_amd.hip_ops.HipOps ->
+libfw_mi355x.so).  The op decomposition follows the reference line by line:
+
+  joint_forward            FantasyWorld/fusion/model_wan21.py:104-224
+  DiTBlock (3 modes)       FantasyWorld/diffsynth_wan21/models/wan_video_dit.py:254-321
+  Self/CrossAttention      wan_video_dit.py:159-243, camera adapter camera_control.py:92-148
+  VGGT Block / Attention   FantasyWorld/vggt/layers/block.py:73-116, attention.py:50-72, rope.py:154-188
+  IRGBlock / bicross       FantasyWorld/fusion/layer/block.py:43-94,179-221,532-625
+  bridge / token assembly  FantasyWorld/vggt/models/vggt.py:118-131, aggregator.py:261-306
+  Head / unpatchify        wan_video_dit.py:344-358,437-442
+
+Numerics: residual streams (DiT x, VGGT tokens) are kept in fp32 (the reference keeps the DiT stream in bf16 and
+the VGGT stream in fp32 after the first modulated block); matmul inputs are bf16, accumulation fp32; all
+normalisation statistics, softmax and rotary math are fp32 (tables from fp64).
+"""
+import math
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .config import FWConfig
+from . import rope as _rope
+
+
+def _pad_to(t, dim, size):
+    if t.shape[dim] == size:
+        return t
+    shape = list(t.shape)
+    shape[dim] = size - t.shape[dim]
+    return torch.cat([t, torch.zeros(shape, dtype=t.dtype, device=t.device)], dim=dim)
+
+
+def _ru64(n):
+    return (n + 63) // 64 * 64
+
+
+class _DitBlock:
+    pass
+
+
+class _VggtBlock:
+    pass
+
+
+class _Bicross:
+    pass
+
+
+class FusionEngine:
+    """Holds the pre-packed weights of one fusion model on one device and runs joint_forward on it."""
+
+    def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None):
+        """`get(name)` returns the reference parameter `name` (any dtype/device); tensors are packed block by block
+        so a 14B model never needs a second full-precision copy.  `shard` is an optional
+        fantasy_world_amd.parallel.SequenceShard (one process per GPU, RCCL)."""
+        self.cfg = cfg
+        self.ops = ops
+        self.shard = shard
+        self._tables = {}
+        self._plucker_zero_cache = None
+        ops_ = ops
+        g = lambda n: get(n).detach().to(torch.float32)
+
+        def lin(wname, bname=None, k_pad=None, n_pad=None):
+            w = g(wname)
+            w = w.reshape(w.shape[0], -1)
+            b = g(bname) if bname else None
+            if k_pad:
+                w = _pad_to(w, 1, k_pad)
+            if n_pad:
+                w = _pad_to(w, 0, n_pad)
+                if b is not None:
+                    b = _pad_to(b, 0, n_pad)
+            return ops_.pack_linear(w, b)
+
+        def lin_cat(names):
+            w = torch.cat([g(n + ".weight") for n in names], dim=0)
+            b = torch.cat([g(n + ".bias") for n in names], dim=0)
+            return ops_.pack_linear(w, b)
+
+        pd = "pipe.dit."
+        self.kpatch = _ru64(cfg.in_dim * 4)
+        self.patch = lin(pd + "patch_embedding.weight", pd + "patch_embedding.bias", k_pad=self.kpatch)
+        self.text0 = lin(pd + "text_embedding.0.weight", pd + "text_embedding.0.bias")
+        self.text2 = lin(pd + "text_embedding.2.weight", pd + "text_embedding.2.bias")
+        self.time0 = ops.pack_linear_f32(g(pd + "time_embedding.0.weight"), g(pd + "time_embedding.0.bias"))
+        self.time2 = ops.pack_linear_f32(g(pd + "time_embedding.2.weight"), g(pd + "time_embedding.2.bias"))
+        self.timep = ops.pack_linear_f32(g(pd + "time_projection.1.weight"), g(pd + "time_projection.1.bias"))
+        if cfg.has_image_input:
+            self.img_ln0 = (ops.to_f32(g(pd + "img_emb.proj.0.weight")), ops.to_f32(g(pd + "img_emb.proj.0.bias")))
+            self.img1 = lin(pd + "img_emb.proj.1.weight", pd + "img_emb.proj.1.bias")
+            self.img3 = lin(pd + "img_emb.proj.3.weight", pd + "img_emb.proj.3.bias")
+            self.img_ln4 = (ops.to_f32(g(pd + "img_emb.proj.4.weight")), ops.to_f32(g(pd + "img_emb.proj.4.bias")))
+        self.head_mod = ops.to_f32(g(pd + "head.modulation").reshape(2, cfg.dim))
+        self.head = lin(pd + "head.head.weight", pd + "head.head.bias")
+        self.dit = [self._pack_dit(b, g, lin, lin_cat) for b in range(cfg.num_layers)]
+
+        self.proj = lin("vggt.projection_head.weight", "vggt.projection_head.bias")
+        cam = g("vggt.aggregator.camera_token")[0]        # [2,1,C]
+        reg = g("vggt.aggregator.register_token")[0]      # [2,4,C]
+        self.special = ops.to_f32(torch.cat([cam, reg], dim=1))   # [2, n_special, C]
+        self.vtime0 = ops.pack_linear_f32(g("vggt.time_embedding.0.weight"), g("vggt.time_embedding.0.bias"))
+        self.vtime2 = ops.pack_linear_f32(g("vggt.time_embedding.2.weight"), g("vggt.time_embedding.2.bias"))
+        self.vtimep = ops.pack_linear_f32(g("vggt.time_projection.1.weight"), g("vggt.time_projection.1.bias"))
+        self.frame = [self._pack_vggt(f"vggt.aggregator.frame_blocks.{j}.", g, lin) for j in range(cfg.n_irg)]
+        self.glob = [self._pack_vggt(cfg.global_prefix(j), g, lin) for j in range(cfg.n_irg)]
+        self.bicross = [self._pack_bicross(f"IRGBlock.{j}.bicross_attention.", g, lin, lin_cat)
+                        for j in range(len(cfg.cross_attention_list))]
+
+    # ------------------------------------------------------------------------------------------------ packing
+    def _pack_dit(self, b, g, lin, lin_cat):
+        cfg, ops = self.cfg, self.ops
+        p = cfg.dit_prefix(b)
+        blk = _DitBlock()
+        blk.index = b
+        blk.mod = ops.to_f32(g(p + "modulation").reshape(6, cfg.dim))
+        blk.qkv = lin_cat([p + "self_attn.q", p + "self_attn.k", p + "self_attn.v"])
+        blk.o = lin(p + "self_attn.o.weight", p + "self_attn.o.bias")
+        blk.norm_q = ops.to_f32(g(p + "self_attn.norm_q.weight"))
+        blk.norm_k = ops.to_f32(g(p + "self_attn.norm_k.weight"))
+        blk.cq = lin(p + "cross_attn.q.weight", p + "cross_attn.q.bias")
+        blk.ckv = lin_cat([p + "cross_attn.k", p + "cross_attn.v"])
+        blk.co = lin(p + "cross_attn.o.weight", p + "cross_attn.o.bias")
+        blk.cnorm_q = ops.to_f32(g(p + "cross_attn.norm_q.weight"))
+        blk.cnorm_k = ops.to_f32(g(p + "cross_attn.norm_k.weight"))
+        if cfg.has_image_input:
+            blk.ckv_img = lin_cat([p + "cross_attn.k_img", p + "cross_attn.v_img"])
+            blk.cnorm_k_img = ops.to_f32(g(p + "cross_attn.norm_k_img.weight"))
+        blk.adapter = cfg.has_adapter(b)
+        if blk.adapter:
+            a = p + "cross_attn.processor."
+            rp = _ru64(cfg.adapter_reduced)
+            blk.a_g1 = lin(a + "k_proj.group1.weight", a + "k_proj.group1.bias")
+            blk.a_g20 = lin(a + "k_proj.group2.0.weight", a + "k_proj.group2.0.bias")
+            blk.a_g22 = lin(a + "k_proj.group2.2.weight", a + "k_proj.group2.2.bias")
+            blk.a_v0 = lin(a + "v_proj.group2.0.weight", a + "v_proj.group2.0.bias", n_pad=rp)   # 409 -> 448 rows (zeros)
+            blk.a_v2 = lin(a + "v_proj.group2.2.weight", a + "v_proj.group2.2.bias", k_pad=rp)   # 409 -> 448 cols (zeros)
+        blk.norm3_w = ops.to_f32(g(p + "norm3.weight"))
+        blk.norm3_b = ops.to_f32(g(p + "norm3.bias"))
+        blk.ffn0 = lin(p + "ffn.0.weight", p + "ffn.0.bias")
+        blk.ffn2 = lin(p + "ffn.2.weight", p + "ffn.2.bias")
+        return blk
+
+    def _pack_vggt(self, p, g, lin):
+        cfg, ops = self.cfg, self.ops
+        blk = _VggtBlock()
+        blk.mod = ops.to_f32(g(p + "modulation").reshape(6, cfg.vggt_dim))
+        blk.norm1 = (ops.to_f32(g(p + "norm1.weight")), ops.to_f32(g(p + "norm1.bias")))
+        blk.qkv = lin(p + "attn.qkv.weight", p + "attn.qkv.bias")
+        blk.q_norm = (ops.to_f32(g(p + "attn.q_norm.weight")), ops.to_f32(g(p + "attn.q_norm.bias")))
+        blk.k_norm = (ops.to_f32(g(p + "attn.k_norm.weight")), ops.to_f32(g(p + "attn.k_norm.bias")))
+        blk.proj = lin(p + "attn.proj.weight", p + "attn.proj.bias")
+        blk.ls1 = ops.to_f32(g(p + "ls1.gamma"))
+        blk.norm2 = (ops.to_f32(g(p + "norm2.weight")), ops.to_f32(g(p + "norm2.bias")))
+        blk.fc1 = lin(p + "mlp.fc1.weight", p + "mlp.fc1.bias")
+        blk.fc2 = lin(p + "mlp.fc2.weight", p + "mlp.fc2.bias")
+        blk.ls2 = ops.to_f32(g(p + "ls2.gamma"))
+        return blk
+
+    def _pack_bicross(self, p, g, lin, lin_cat):
+        ops = self.ops
+        bc = _Bicross()
+        c = p + "cross_attn."
+        bc.qv1 = lin_cat([c + "m1_proj", c + "values_m1_proj"])      # x_dit -> [q | v1]
+        bc.kv2 = lin_cat([c + "m2_proj", c + "values_m2_proj"])      # x_agg -> [k | v2]
+        bc.out1 = lin(c + "out_m1_proj.weight", c + "out_m1_proj.bias")
+        bc.out2 = lin(c + "out_m2_proj.weight", c + "out_m2_proj.bias")
+        bc.gamma1 = ops.to_f32(g(p + "gamma_m1"))
+        bc.gamma2 = ops.to_f32(g(p + "gamma_m2"))
+        return bc
+
+    # ------------------------------------------------------------------------------------------------ tables
+    def _get_tables(self, f, h, w):
+        key = (f, h, w)
+        if key not in self._tables:
+            cfg, ops = self.cfg, self.ops
+            bhd = cfg.bicross_dim // cfg.bicross_heads
+            t = dict(
+                dit=ops.to_f32(_rope.rope3d_table(cfg.head_dim, f, h, w)),
+                bi_dit=ops.to_f32(_rope.rope3d_table(bhd, f, h, w)),
+                bi_agg=ops.to_f32(_rope.rope3d_table_with_extra(bhd, f, h, w, cfg.n_special)),
+                vggt=ops.to_f32(_rope.rope2d_table(cfg.vggt_dim // cfg.vggt_heads, h, w, cfg.n_special,
+                                                   cfg.vggt_rope_freq)),
+            )
+            self._tables = {key: t}     # keep only the latest grid
+        return self._tables[key]
+
+    # ------------------------------------------------------------------------------------------------ blocks
+    def _dit_attn(self, blk, x, ctx_txt, ctx_img, t_mod, tabs, plucker):
+        """Self-attention + cross-attention (+ camera adapter): DiTBlock.forward up to `return_partial`
+        (wan_video_dit.py:296-306).  x: fp32 residual stream [L, D], updated in place."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
+        mod = blk.mod + t_mod                                    # [6, D]: shift/scale/gate msa, shift/scale/gate mlp
+        xn = ops.layernorm(x, scale=mod[1], shift=mod[0], eps=cfg.eps)
+        qkv = ops.linear(xn, blk.qkv)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        tab = tabs["dit"] if sh is None else tabs["dit_local"]
+        ops.qk_prep(q, H, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab)
+        ops.qk_prep(k, H, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab)
+        if sh is not None:
+            kv = sh.all_gather_rows(qkv[:, D:], sh.dit_counts)   # [L, 2D] (k | v) of every rank
+            k, v = kv[:, :D], kv[:, D:]
+        o = ops.attention(q, k, v, H, hd)
+        ops.linear(o, blk.o, g1=mod[2], res=x, out_f32=True, out=x)
+        # cross-attention: text + image keys share q; outputs are summed (wan_video_dit.py:185-201)
+        xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
+        qc = ops.linear(xn3, blk.cq)
+        ops.qk_prep(qc, H, hd, norm="rms_full", norm_w=blk.cnorm_q, eps=cfg.eps)
+        kv = ops.linear(ctx_txt, blk.ckv)
+        ops.qk_prep(kv[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k, eps=cfg.eps)
+        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd)
+        if ctx_img is not None:
+            kvi = ops.linear(ctx_img, blk.ckv_img)
+            ops.qk_prep(kvi[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k_img, eps=cfg.eps)
+            ops.attention(qc, kvi[:, :D], kvi[:, D:], H, hd, out=oc, accumulate=True)
+        if blk.adapter and plucker is not None:
+            # camera_control.py:109-127 ('adaln'): scale == 0 identically, so x <- x + shift
+            t1 = ops.linear(oc, blk.a_g20, act="relu")
+            pterm = ops.linear(plucker, blk.a_g1)
+            comb = ops.linear(t1, blk.a_g22, res=pterm, out=pterm)
+            t2 = ops.linear(comb, blk.a_v0, act="relu")
+            ops.linear(t2, blk.a_v2, res=oc, out=oc)
+        ops.linear(oc, blk.co, res=x, out_f32=True, out=x)
+        return mod
+
+    def _dit_ffn(self, blk, x, mod):
+        """FFN half (`run_remaining`, wan_video_dit.py:288-294)."""
+        cfg, ops = self.cfg, self.ops
+        xn = ops.layernorm(x, scale=mod[4], shift=mod[3], eps=cfg.eps)
+        hbuf = ops.linear(xn, blk.ffn0, act="gelu_tanh")
+        ops.linear(hbuf, blk.ffn2, g1=mod[5], res=x, out_f32=True, out=x)
+
+    def _vggt_attn(self, blk, tok, e0, tabs, batch, frame_mode):
+        """Attention half of vggt Block.forward (block.py:73-76,99-107).  tok: fp32 [rows, C] in place."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        C, H = cfg.vggt_dim, cfg.vggt_heads
+        hd = C // H
+        e = blk.mod + e0                                         # [6, C]; e[2] is never used (block.py:73-81)
+        xn = ops.layernorm(tok, w=blk.norm1[0], b=blk.norm1[1], scale=e[1], shift=e[0], eps=cfg.vggt_eps)
+        qkv = ops.linear(xn, blk.qkv)
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        ops.qk_prep(q, H, hd, norm="ln_head", norm_w=blk.q_norm[0], norm_b=blk.q_norm[1], eps=cfg.vggt_eps,
+                    rope="half2d", table=tabs["vggt"])
+        ops.qk_prep(k, H, hd, norm="ln_head", norm_w=blk.k_norm[0], norm_b=blk.k_norm[1], eps=cfg.vggt_eps,
+                    rope="half2d", table=tabs["vggt"])
+        if not frame_mode and sh is not None:
+            kv = sh.all_gather_rows(qkv[:, C:], sh.agg_counts)
+            k, v = kv[:, :C], kv[:, C:]
+        o = ops.attention(q, k, v, H, hd, batch=batch)
+        ops.linear(o, blk.proj, g1=blk.ls1, res=tok, out_f32=True, out=tok)
+        return e
+
+    def _vggt_mlp(self, blk, tok, e):
+        """MLP half: x += (ls2(mlp(norm2(x)) * (1 + e4) + e3)) * e5 -- modulation AFTER the MLP (block.py:78-81)."""
+        cfg, ops = self.cfg, self.ops
+        xn = ops.layernorm(tok, w=blk.norm2[0], b=blk.norm2[1], eps=cfg.vggt_eps)
+        hbuf = ops.linear(xn, blk.fc1, act="gelu_erf")
+        g1 = blk.ls2 * (1.0 + e[4]) * e[5]
+        g0 = blk.ls2 * e[3] * e[5]
+        ops.linear(hbuf, blk.fc2, g1=g1, g0=g0, res=tok, out_f32=True, out=tok)
+
+    def _bicross(self, bc, x, tok, tabs):
+        """CrossModalityBiAttentionBlock (fusion/layer/block.py:179-221) with BiMultiHeadAttention.forward_sdpa
+        (block.py:532-625): both directions, residuals scaled by gamma_m1 / gamma_m2."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        Bd, Hb = cfg.bicross_dim, cfg.bicross_heads
+        hd = Bd // Hb
+        a = ops.layernorm(x, eps=1e-6)
+        b = ops.layernorm(tok, eps=1e-6)
+        qv1 = ops.linear(a, bc.qv1)          # [L, 2*Bd]  q | v1
+        kv2 = ops.linear(b, bc.kv2)          # [L2, 2*Bd] k | v2
+        ops.qk_prep(qv1[:, :Bd], Hb, hd, rope="interleaved", table=tabs["bi_dit"] if sh is None else tabs["bi_dit_local"])
+        ops.qk_prep(kv2[:, :Bd], Hb, hd, rope="interleaved", table=tabs["bi_agg"] if sh is None else tabs["bi_agg_local"])
+        q_loc, k_loc = qv1[:, :Bd], kv2[:, :Bd]
+        if sh is not None:
+            qv1_all = sh.all_gather_rows(qv1, sh.dit_counts)
+            kv2_all = sh.all_gather_rows(kv2, sh.agg_counts)
+        else:
+            qv1_all, kv2_all = qv1, kv2
+        o1 = ops.attention(q_loc, kv2_all[:, :Bd], kv2_all[:, Bd:], Hb, hd)      # softmax(q k^T) v2
+        o2 = ops.attention(k_loc, qv1_all[:, :Bd], qv1_all[:, Bd:], Hb, hd)      # softmax(k q^T) v1
+        ops.linear(o1, bc.out1, g1=bc.gamma1, res=x, out_f32=True, out=x)
+        ops.linear(o2, bc.out2, g1=bc.gamma2, res=tok, out_f32=True, out=tok)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def joint_forward(self, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
+                      plucker_context_lens=None, uncond=False, return_prediction=False, camera_token=None,
+                      collect=None):
+        """Returns (noise_pred [1,16,F,H,W] in x.dtype, output_list or None).
+
+        output_list (only when return_prediction): dict layer -> fp32 [1, S, P, 2*C] for the layers the geometry
+        heads read (dpt_head.py:44 -> 23,17,11,7 and camera_head.py:89 -> last); the heads themselves stay with the
+        caller (fantasy_world_amd.install wires them to the reference's vggt._head_predction).
+        `collect`: optional dict that receives intermediate tensors (tests).
+        """
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        if camera_token is not None:
+            raise NotImplementedError("camera_token != None (CamTokenProjector path) is not used by the reference "
+                                      "inference scripts and is not implemented")
+        assert x.shape[0] == 1, "the reference samples with batch 1 (model_wan21.py:254-258)"
+        F, H2, W2 = x.shape[2:]
+        h, w = H2 // 2, W2 // 2
+        hw = h * w
+        L = F * hw
+        P = cfg.n_special + hw
+        tabs = self._get_tables(F, h, w)
+        if sh is not None:
+            tabs = sh.localize_tables(tabs, F, hw, cfg.n_special)
+
+        # ---- A1: time embeddings, fp32 (wan_video_dit.py:393-399, vggt.py:126-130) ----------------------------
+        sin = ops.sinusoid(timestep, cfg.freq_dim)
+        t = ops.linear_f32(ops.linear_f32(sin, self.time0, act="silu"), self.time2)           # [D]
+        t_mod = ops.linear_f32(t, self.timep, silu_in=True).view(6, cfg.dim)
+        ev = ops.linear_f32(ops.linear_f32(sin, self.vtime0, act="silu"), self.vtime2)
+        e0 = ops.linear_f32(ev, self.vtimep, silu_in=True).view(6, cfg.vggt_dim)
+
+        # ---- A2: context embeddings (wan_video_dit.py:388-392, 324-341) ----------------------------------------
+        ctx_txt = ops.linear(ops.linear(ops.to_act(context[0]), self.text0, act="gelu_tanh"), self.text2)
+        ctx_img = None
+        if cfg.has_image_input:
+            ci = ops.layernorm(ops.to_act(clip_feature[0]), w=self.img_ln0[0], b=self.img_ln0[1], eps=1e-5)
+            ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
+            ctx_img = ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
+
+        # ---- A3: patchify (Conv3d k=s=(1,2,2) as GEMM) ---------------------------------------------------------
+        patches = ops.patchify(x, y if cfg.has_image_input else None, self.kpatch)            # [L, 192]
+        plucker = None
+        if plucker_fea is not None and cfg.camera_adapter:
+            if not self._plucker_all_zero(plucker_fea):                                        # camera_control.py:111
+                plucker = ops.to_act(plucker_fea[0])
+        if sh is not None:
+            patches = sh.take_dit_rows(patches)
+            plucker = None if plucker is None else sh.take_dit_rows(plucker)
+        xs = ops.linear(patches, self.patch, out_f32=True)                                    # fp32 residual stream
+
+        # ---- PCB: DiT blocks [0, start_index) ------------------------------------------------------------------
+        for b in range(cfg.start_index):
+            blk = self.dit[b]
+            mod = self._dit_attn(blk, xs, ctx_txt, ctx_img, t_mod, tabs, plucker)
+            self._dit_ffn(blk, xs, mod)
+        if collect is not None:
+            collect["x_after_pcb"] = xs.clone()
+
+        # ---- bridge: DiT tokens -> VGGT tokens (model_wan21.py:170-175) -----------------------------------------
+        ptok = ops.linear(ops.cast_act(xs), self.proj)                                         # [L(local), C]
+        if sh is not None:
+            ptok = sh.dit_rows_to_frames(ptok, hw)                                             # this rank's frames
+            S_loc = sh.my_frames
+        else:
+            S_loc = F
+        tok = ops.assemble_tokens(ptok, self._special_for(sh), S_loc, hw)                      # fp32 [S_loc*P, C]
+        if collect is not None:
+            collect["tokens_in"] = tok.clone()
+
+        need = set()
+        if return_prediction:
+            need = {7, 11, 17, 23, cfg.n_irg - 1}
+        outputs = {}
+        for i in range(cfg.n_irg):
+            fb = self.frame[i]
+            e = self._vggt_attn(fb, tok, e0, tabs, batch=S_loc, frame_mode=True)
+            self._vggt_mlp(fb, tok, e)
+            frame_out = tok.clone() if i in need else None
+            blk = self.dit[cfg.start_index + i]
+            gb = self.glob[i]
+            mod = self._dit_attn(blk, xs, ctx_txt, ctx_img, t_mod, tabs, plucker)
+            e = self._vggt_attn(gb, tok, e0, tabs, batch=1, frame_mode=False)
+            if i in cfg.cross_attention_list and not uncond:
+                self._bicross(self.bicross[i], xs, tok, tabs)
+            self._dit_ffn(blk, xs, mod)
+            self._vggt_mlp(gb, tok, e)
+            if i in need:
+                outputs[i] = torch.cat([frame_out.view(1, S_loc, P, -1), tok.view(1, S_loc, P, -1)], dim=-1)
+        if collect is not None:
+            collect["x_final"] = xs.clone()
+            collect["tokens_final"] = tok.clone()
+
+        # ---- head (wan_video_dit.py:344-358) + unpatchify -------------------------------------------------------
+        xn = ops.layernorm(xs, scale=self.head_mod[1] + t, shift=self.head_mod[0] + t, eps=cfg.eps)
+        hd_out = ops.linear(xn, self.head, out_f32=True)                                       # [L(local), 64]
+        if sh is not None:
+            hd_out = sh.all_gather_rows(hd_out, sh.dit_counts)
+        out = ops.unpatchify(hd_out, F, h, w, x.dtype)
+        if return_prediction:
+            if sh is not None:
+                outputs = {k: sh.gather_frames(v) for k, v in outputs.items()}
+            return out, outputs
+        return out, None
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _special_for(self, sh):
+        if sh is None or sh.first_frame == 0:
+            return self.special
+        # ranks that do not own frame 0 only ever use the "other frames" variant (aggregator.py:283-306)
+        return torch.stack([self.special[1], self.special[1]], dim=0).contiguous()
+
+    def _plucker_all_zero(self, plucker_fea):
+        key = (plucker_fea.data_ptr(), tuple(plucker_fea.shape), plucker_fea._version)
+        if self._plucker_zero_cache is None or self._plucker_zero_cache[0] != key:
+            # one host sync per NEW plucker tensor (the reference syncs 25x per forward, camera_control.py:111)
+            self._plucker_zero_cache = (key, bool((plucker_fea == 0).all().item()))
+        return self._plucker_zero_cache[1]

@@ -1,0 +1,261 @@
+"""ctypes binding of libfw_mi355x.so (include/fw_mi355x.h) + the op set the engine is written against.
+
+PyTorch is used here only as the owner of device memory and of the HIP stream; every arithmetic op of the
+denoising forward goes through the C ABI.  There is NO fallback: if the shared library is missing, or no gfx950
+device is visible, construction raises.
+"""
+import ctypes
+import math
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfw_mi355x.so")
+
+FW_DT_NONE, FW_DT_BF16, FW_DT_F32 = 0, 1, 2
+ACT = {None: 0, "none": 0, "relu": 1, "gelu_tanh": 2, "gelu_erf": 3, "silu": 4}
+NORM = {None: 0, "none": 0, "rms_full": 1, "ln_head": 2}
+ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
+
+# every symbol declared in include/fw_mi355x.h (tests check the library exports all of them)
+SYMBOLS = [
+    "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
+    "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
+    "fw_cast_f32_bf16",
+]
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the C-ABI library and declare argument types.  Raises if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The HIP path has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    c = ctypes
+    vp, i64, i32, f32 = c.c_void_p, c.c_int64, c.c_int, c.c_float
+    lib.fw_abi_version.restype = i32
+    lib.fw_abi_version.argtypes = []
+    lib.fw_last_error.restype = c.c_char_p
+    lib.fw_last_error.argtypes = []
+    sig = {
+        "fw_gemm_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
+        "fw_attention_bf16": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, i32, vp],
+        "fw_v_transpose": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
+        "fw_layernorm_mod": [vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp],
+        "fw_qk_prep": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, vp],
+        "fw_gemv_f32": [vp, vp, i64, vp, vp, i32, i32, i32, i32, vp],
+        "fw_sinusoid": [vp, i32, vp, i32, vp],
+        "fw_patchify": [vp, i32, vp, i32, i32, vp, i64, i32, i32, i32, vp],
+        "fw_unpatchify": [vp, i64, vp, i32, i32, i32, i32, vp],
+        "fw_assemble_tokens": [vp, i64, vp, vp, i32, i32, i32, i32, vp],
+        "fw_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = args
+    if lib.fw_abi_version() != 1:
+        raise RuntimeError("libfw_mi355x.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _lib.fw_last_error().decode() if rc < 0 else f"hipError {rc}"
+        raise RuntimeError(f"{what} failed: {msg}")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return FW_DT_BF16
+    if t.dtype == torch.float32:
+        return FW_DT_F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+class Linear:
+    """Pre-packed nn.Linear: bf16 weight [N, K] (K % 64 == 0, zero padded), fp32 bias [N]."""
+    __slots__ = ("w", "b", "N", "K")
+
+    def __init__(self, w, b):
+        self.w, self.b = w, b
+        self.N, self.K = w.shape
+
+
+class LinearF32:
+    __slots__ = ("w", "b", "N", "K")
+
+    def __init__(self, w, b):
+        self.w, self.b = w, b
+        self.N, self.K = w.shape
+
+
+class HipOps:
+    """The engine's op set on one MI355X.  Activations are bf16; residual streams and statistics are fp32."""
+
+    name = "hip"
+    act_dtype = torch.bfloat16
+
+    def __init__(self, device="cuda"):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs a visible gfx950 device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipOps only runs on a HIP device")
+
+    # ---- memory plumbing ------------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.act_dtype, device=self.device)
+
+    def to_f32(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def to_act(self, t):
+        return t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+
+    def pack_linear(self, w, b):
+        """w fp32/bf16 [N, K] with K % 64 == 0 (engine pads), b [N] or None."""
+        assert w.shape[1] % 64 == 0, w.shape
+        wb = w.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        bb = None if b is None else b.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        return Linear(wb, bb)
+
+    def pack_linear_f32(self, w, b):
+        return LinearF32(self.to_f32(w), None if b is None else self.to_f32(b))
+
+    # ---- GEMM -------------------------------------------------------------------------------------------------
+    def linear(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1, (x.dtype, x.shape, x.stride())
+        M, K = x.shape
+        assert K == lin.K, (K, lin.K)
+        if out is None:
+            out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
+        assert out.shape == (M, lin.N) and out.stride(1) == 1
+        if res is not None:
+            assert res.shape == (M, lin.N) and res.stride(1) == 1
+        _check(self.lib.fw_gemm_bf16(
+            x.data_ptr(), x.stride(0), lin.w.data_ptr(), lin.w.stride(0), out.data_ptr(), out.stride(0), _dt(out),
+            M, lin.N, K, _ptr(lin.b), ACT[act], _ptr(g1), _ptr(g0),
+            _ptr(res), 0 if res is None else res.stride(0), FW_DT_NONE if res is None else _dt(res),
+            self._stream()), "fw_gemm_bf16")
+        return out
+
+    def linear_f32(self, x, lin, silu_in=False, act=None):
+        assert x.dtype == torch.float32 and x.numel() == lin.K
+        out = torch.empty(lin.N, dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_gemv_f32(x.data_ptr(), lin.w.data_ptr(), lin.w.stride(0), _ptr(lin.b), out.data_ptr(),
+                                    lin.N, lin.K, int(silu_in), ACT[act], self._stream()), "fw_gemv_f32")
+        return out
+
+    # ---- norms ------------------------------------------------------------------------------------------------
+    def layernorm(self, x, w=None, b=None, scale=None, shift=None, eps=1e-6, out=None):
+        assert x.dim() == 2 and x.stride(1) == 1
+        rows, C = x.shape
+        if out is None:
+            out = torch.empty(rows, C, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_layernorm_mod(x.data_ptr(), x.stride(0), _dt(x), out.data_ptr(), out.stride(0), rows, C,
+                                         _ptr(w), _ptr(b), _ptr(scale), _ptr(shift), float(eps), self._stream()),
+               "fw_layernorm_mod")
+        return out
+
+    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None):
+        """In place on x [rows, heads*hd] (may be a column slice of a wider buffer)."""
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == heads * hd
+        tab_rows = 0 if table is None else table.shape[0]
+        if table is not None:
+            assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1:] == (hd // 2, 2)
+        _check(self.lib.fw_qk_prep(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, NORM[norm], _ptr(norm_w),
+                                   _ptr(norm_b), float(eps), ROPE[rope], _ptr(table), tab_rows, self._stream()),
+               "fw_qk_prep")
+        return x
+
+    # ---- attention ----------------------------------------------------------------------------------------------
+    def prepare_v(self, v, heads, hd, batch=1):
+        """v [batch*Lk, heads*hd] (strided ok) -> key-permuted transposed copy the attention kernel consumes."""
+        assert v.dtype == torch.bfloat16 and v.stride(1) == 1
+        Lk = v.shape[0] // batch
+        lkp = (Lk + 63) // 64 * 64
+        vt = torch.empty(batch, heads, hd, lkp, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_v_transpose(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads,
+                                       hd, Lk, self._stream()), "fw_v_transpose")
+        return vt, Lk
+
+    def attention(self, q, k, v, heads, hd, batch=1, out=None, accumulate=False, v_prepared=None):
+        """softmax(q k^T / sqrt(hd)) v per (batch, head); q [batch*Lq, heads*hd], k/v [batch*Lk, heads*hd]."""
+        assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and q.stride(1) == 1 and k.stride(1) == 1
+        Lq = q.shape[0] // batch
+        Lk = k.shape[0] // batch
+        vt, lk2 = v_prepared if v_prepared is not None else self.prepare_v(v, heads, hd, batch)
+        assert lk2 == Lk
+        if out is None:
+            out = torch.empty(batch * Lq, heads * hd, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_attention_bf16(
+            q.data_ptr(), q.stride(0), Lq * q.stride(0), k.data_ptr(), k.stride(0), Lk * k.stride(0),
+            vt.data_ptr(), vt.shape[-1], out.data_ptr(), out.stride(0), Lq * out.stride(0),
+            batch, heads, hd, Lq, Lk, 1.0 / math.sqrt(hd), int(accumulate), self._stream()), "fw_attention_bf16")
+        return out
+
+    # ---- embeddings / layout ------------------------------------------------------------------------------------
+    def sinusoid(self, t, dim):
+        """t: 1-element device tensor (bf16 or f32) -> fp32 [dim] (fp64 math on device, no host sync)."""
+        t = t.reshape(-1)[:1].contiguous()
+        if t.dtype not in (torch.bfloat16, torch.float32):
+            t = t.to(torch.float32)
+        out = torch.empty(dim, dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_sinusoid(t.data_ptr(), _dt(t), out.data_ptr(), dim, self._stream()), "fw_sinusoid")
+        return out
+
+    def patchify(self, x, y, kpad):
+        """x [1,Cx,F,H2,W2], y [1,Cy,F,H2,W2] or None -> bf16 [L, kpad]."""
+        x = x.contiguous()
+        if x.dtype not in (torch.bfloat16, torch.float32):
+            x = x.float()
+        _, cx, F, H2, W2 = x.shape
+        cy = 0
+        if y is not None:
+            y = y.to(x.dtype).contiguous()
+            cy = y.shape[1]
+        L = F * (H2 // 2) * (W2 // 2)
+        out = torch.empty(L, kpad, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_patchify(x.data_ptr(), cx, _ptr(y), cy, _dt(x), out.data_ptr(), kpad, F, H2, W2,
+                                    self._stream()), "fw_patchify")
+        return out
+
+    def unpatchify(self, hd_out, F, Hh, Ww, out_dtype):
+        assert hd_out.dtype == torch.float32 and hd_out.shape[1] == 64 and hd_out.stride(1) == 1
+        out = torch.empty(1, 16, F, 2 * Hh, 2 * Ww, dtype=out_dtype, device=self.device)
+        _check(self.lib.fw_unpatchify(hd_out.data_ptr(), hd_out.stride(0), out.data_ptr(), _dt(out), F, Hh, Ww,
+                                      self._stream()), "fw_unpatchify")
+        return out
+
+    def assemble_tokens(self, patch, special, S, hw):
+        """patch bf16 [S*hw, C]; special fp32 [2, n_special, C] -> fp32 [S*(n_special+hw), C]."""
+        n_special, C = special.shape[1], special.shape[2]
+        out = torch.empty(S * (n_special + hw), C, dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_assemble_tokens(patch.data_ptr(), patch.stride(0), special.data_ptr(), out.data_ptr(),
+                                           S, hw, n_special, C, self._stream()), "fw_assemble_tokens")
+        return out
+
+    def cast_act(self, x):
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_cast_f32_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0],
+                                         x.shape[1], self._stream()), "fw_cast_f32_bf16")
+        return out

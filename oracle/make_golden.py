@@ -1,0 +1,98 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.pt by running the REAL reference (imported from
+/root/reference through oracle/ref_harness.py) on deterministic synthetic weights and inputs, and check that
+oracle/fw_oracle.py reproduces it.  Runs only in the build container:
+
+    python oracle/make_golden.py            # writes tests/golden/wan21_*.pt, prints oracle-vs-reference errors
+
+The fixtures hold only small tensors (outputs and a few intermediate activations); weights and inputs are
+regenerated from seeds by fantasy_world_amd.synth on whatever machine runs the tests.
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from fantasy_world_amd import config as fwc, synth   # noqa: E402
+from oracle import fw_oracle, ref_harness            # noqa: E402
+
+CASES = {
+    # name: (cfg kwargs, (f, h2, w2), timestep, text_len, uncond)
+    "wan21_l2_f3_8x8": (dict(num_layers=2, start_index=1), (3, 8, 8), 500.0, 512, False),
+    "wan21_l3_f2_12x8": (dict(num_layers=3, start_index=1), (2, 12, 8), 937.5, 512, False),
+}
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+def run_reference(cfg, W, ins, uncond=False):
+    model = ref_harness.build_reference_wan21(cfg, weights=W)
+    cap = {}
+
+    def hook_pcb(m, a, out):
+        cap["x_after_pcb"] = out[0].detach().clone()
+
+    def hook_irg(m, a, out):
+        cap["x_final"] = out[0][0].detach().clone()
+        cap["tokens_final"] = out[1][0].detach().clone()
+
+    model.pipe.dit.blocks[cfg.start_index - 1].register_forward_hook(hook_pcb)
+    model.IRGBlock[len(cfg.cross_attention_list) - 1].register_forward_hook(hook_irg)
+    with torch.no_grad():
+        out, pred = model.joint_forward(
+            ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"],
+            y=ins["y"], use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+            plucker_context_lens=ins["plucker_context_lens"], uncond=uncond, return_prediction=False)
+    assert pred is None
+    cap["noise_pred"] = out.detach().clone()
+    return cap, model
+
+
+def main():
+    torch.manual_seed(0)
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    for name, (ckw, (f, h2, w2), ts, tl, uncond) in CASES.items():
+        cfg = fwc.plumbing(**ckw)
+        t0 = time.time()
+        W = synth.make_weights(cfg)
+        ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=ts, text_len=tl)
+        print(f"[{name}] weights {sum(v.numel() for v in W.values())/1e9:.2f} B params in {time.time()-t0:.1f}s")
+        t0 = time.time()
+        ref, model = run_reference(cfg, W, ins, uncond)
+        print(f"[{name}] reference forward {time.time()-t0:.1f}s; unused synth names: {model._fw_unused[:5]} "
+              f"(n={len(model._fw_unused)}); hot-path names missing from synth: "
+              f"{[m for m in model._fw_missing if not _cold(m)][:8]}")
+        assert not model._fw_unused, "synth produced names the reference does not have"
+        assert not [m for m in model._fw_missing if not _cold(m)], "synth misses hot-path parameters"
+        del model
+        col = {}
+        t0 = time.time()
+        orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
+                                      ins["plucker_fea"], ins["plucker_context_lens"], uncond=uncond, collect=col)
+        print(f"[{name}] oracle forward {time.time()-t0:.1f}s")
+        col["noise_pred"] = orc
+        for k in ("x_after_pcb", "x_final", "tokens_final", "noise_pred"):
+            print(f"   oracle vs reference  {k:14s} rel-L2 = {rel(col[k], ref[k]):.3e}   |ref| = {ref[k].norm():.3f}")
+        # a second timestep draw through the negative-prompt context (the CFG pair of one denoise step)
+        golden = {k: v.to(torch.float32).contiguous() for k, v in ref.items()}
+        golden["meta"] = dict(cfg=ckw, grid=(f, h2, w2), timestep=ts, text_len=tl, uncond=uncond, seed_weights=0,
+                              seed_inputs=1, torch=torch.__version__)
+        path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+        torch.save(golden, path)
+        print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
+def _cold(name):
+    """Parameters that are not on the per-step hot path (geometry heads, pose encoder, CamTokenProjector)."""
+    return (name.startswith("vggt.camera_head") or name.startswith("vggt.depth_head") or
+            name.startswith("vggt.point_head") or name.startswith("camera_condition.pose_encoder") or
+            "CamTokenProjector" in name)
+
+
+if __name__ == "__main__":
+    main()

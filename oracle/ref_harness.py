@@ -141,6 +141,7 @@ def build_reference_wan21(cfg, weights=None):
     if weights is not None:
         # RoPE tables are plain attributes (not buffers): rebuild them off the meta device
         dit.freqs = precompute_freqs_cis_3d(cfg.dim // cfg.num_heads)
+        vggt.aggregator.freqs = torch.zeros(1)   # unused by the fusion path (only moved across devices, AGG:272)
     sched = FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True)
     model.pipe = _FakePipe(dit, sched)
     model.vggt = vggt

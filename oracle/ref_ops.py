@@ -1,0 +1,182 @@
+"""TEST INFRASTRUCTURE ONLY -- plain-PyTorch (CPU, fp32) implementation of the engine's op set.
+
+Lets the host-side orchestration of fantasy_world_amd.engine (op order, weight packing/padding, modulation algebra,
+rotary tables, sequence sharding) be checked on a machine without a GPU, against oracle/fw_oracle.py and the golden
+fixtures.  It is never constructed by the product: fantasy_world_amd.install()/bench.py only ever build HipOps, which
+raises when libfw_mi355x.so or the GPU is missing.  Each method restates the arithmetic of the matching C-ABI entry
+point (include/fw_mi355x.h) and is what the `-m gpu` op tests compare the HIP kernels with.
+
+`emulate_bf16=True` rounds activations to bf16 at the points where the HIP path stores bf16, which gives the
+tolerance tests a realistic yardstick of the rounding the GPU path is allowed.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class _Lin:
+    __slots__ = ("w", "b", "N", "K")
+
+    def __init__(self, w, b):
+        self.w, self.b = w, b
+        self.N, self.K = w.shape
+
+
+class TorchRefOps:
+    name = "torch-ref"
+
+    def __init__(self, emulate_bf16=False, device="cpu"):
+        self.emulate_bf16 = emulate_bf16
+        self.device = torch.device(device)
+        self.act_dtype = torch.float32
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------
+    def _r(self, t):
+        return t.to(torch.bfloat16).to(torch.float32) if self.emulate_bf16 else t
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or torch.float32, device=self.device)
+
+    def to_f32(self, t):
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def to_act(self, t):
+        return self._r(t.detach().to(device=self.device, dtype=torch.float32)).contiguous()
+
+    def pack_linear(self, w, b):
+        assert w.shape[1] % 64 == 0
+        return _Lin(self._r(self.to_f32(w)), None if b is None else self.to_f32(b))
+
+    def pack_linear_f32(self, w, b):
+        return _Lin(self.to_f32(w), None if b is None else self.to_f32(b))
+
+    # ---- ops --------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _act(y, act):
+        if act in (None, "none"):
+            return y
+        if act == "relu":
+            return F.relu(y)
+        if act == "gelu_tanh":
+            return F.gelu(y, approximate="tanh")
+        if act == "gelu_erf":
+            return F.gelu(y)
+        if act == "silu":
+            return F.silu(y)
+        raise ValueError(act)
+
+    def linear(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
+        assert x.shape[1] == lin.K
+        y = x.to(torch.float32) @ lin.w.t()
+        if lin.b is not None:
+            y = y + lin.b
+        y = self._act(y, act)
+        if g1 is not None:
+            y = y * g1
+        if g0 is not None:
+            y = y + g0
+        if res is not None:
+            y = y + res
+        if not out_f32:
+            y = self._r(y)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def linear_f32(self, x, lin, silu_in=False, act=None):
+        x = x.reshape(-1).to(torch.float32)
+        if silu_in:
+            x = F.silu(x)
+        y = lin.w @ x
+        if lin.b is not None:
+            y = y + lin.b
+        return self._act(y, act)
+
+    def layernorm(self, x, w=None, b=None, scale=None, shift=None, eps=1e-6, out=None):
+        y = F.layer_norm(x.to(torch.float32), (x.shape[-1],), w, b, eps)
+        if scale is not None:
+            y = y * (1.0 + scale)
+        if shift is not None:
+            y = y + shift
+        return self._r(y)
+
+    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None):
+        rows = x.shape[0]
+        v = x.to(torch.float32)
+        if norm == "rms_full":
+            v = v * torch.rsqrt(v.pow(2).mean(dim=-1, keepdim=True) + eps) * norm_w
+        elif norm == "ln_head":
+            v = F.layer_norm(v.view(rows, heads, hd), (hd,), norm_w, norm_b, eps).reshape(rows, heads * hd)
+        if rope not in (None, "none"):
+            tab = table[torch.arange(rows) % table.shape[0]]          # [rows, hd/2, 2]
+            cs, sn = tab[..., 0].unsqueeze(1), tab[..., 1].unsqueeze(1)  # [rows, 1, hd/2]
+            vh = v.view(rows, heads, hd)
+            if rope == "interleaved":
+                a, bq = vh[..., 0::2], vh[..., 1::2]
+                o = torch.stack([a * cs - bq * sn, a * sn + bq * cs], dim=-1).reshape(rows, heads, hd)
+            elif rope == "half2d":
+                q4 = hd // 4
+                vv = vh.view(rows, heads, 2, 2, q4)                      # [.., half(y/x), lo/hi, q4]
+                c2 = cs.view(rows, 1, 2, q4)
+                s2 = sn.view(rows, 1, 2, q4)
+                lo, hi_ = vv[:, :, :, 0], vv[:, :, :, 1]
+                o = torch.stack([lo * c2 - hi_ * s2, hi_ * c2 + lo * s2], dim=3).reshape(rows, heads, hd)
+            else:
+                raise ValueError(rope)
+            v = o.reshape(rows, heads * hd)
+        x.copy_(self._r(v))
+        return x
+
+    def prepare_v(self, v, heads, hd, batch=1):
+        return (v, v.shape[0] // batch)
+
+    def attention(self, q, k, v, heads, hd, batch=1, out=None, accumulate=False, v_prepared=None):
+        if v_prepared is not None:
+            v = v_prepared[0]
+        Lq, Lk = q.shape[0] // batch, k.shape[0] // batch
+        qh = q.reshape(batch, Lq, heads, hd).transpose(1, 2).to(torch.float32)
+        kh = k.reshape(batch, Lk, heads, hd).transpose(1, 2).to(torch.float32)
+        vh = v.reshape(batch, Lk, heads, hd).transpose(1, 2).to(torch.float32)
+        s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
+        o = torch.softmax(s, dim=-1) @ vh
+        o = o.transpose(1, 2).reshape(batch * Lq, heads * hd)
+        if accumulate:
+            o = o + out
+        o = self._r(o)
+        if out is not None:
+            out.copy_(o)
+            return out
+        return o
+
+    def sinusoid(self, t, dim):
+        half = dim // 2
+        pos = t.reshape(-1)[:1].to(torch.float64)
+        freq = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half)
+        a = pos * freq
+        return torch.cat([torch.cos(a), torch.sin(a)]).to(torch.float32)
+
+    def patchify(self, x, y, kpad):
+        xy = x if y is None else torch.cat([x, y.to(x.dtype)], dim=1)
+        xy = xy.to(torch.float32)
+        _, C, F_, H2, W2 = xy.shape
+        h, w = H2 // 2, W2 // 2
+        p = xy[0].view(C, F_, h, 2, w, 2).permute(1, 2, 4, 0, 3, 5).reshape(F_ * h * w, C * 4)
+        out = torch.zeros(F_ * h * w, kpad)
+        out[:, : C * 4] = p
+        return self._r(out)
+
+    def unpatchify(self, hd_out, F_, Hh, Ww, out_dtype):
+        t = hd_out.view(F_, Hh, Ww, 1, 2, 2, 16)            # (f h w) (x y z c)
+        t = t.permute(6, 0, 3, 1, 4, 2, 5).reshape(16, F_, 2 * Hh, 2 * Ww)
+        return t.unsqueeze(0).to(out_dtype)
+
+    def assemble_tokens(self, patch, special, S, hw):
+        n_special, C = special.shape[1], special.shape[2]
+        pt = patch.to(torch.float32).view(S, hw, C)
+        sp = torch.stack([special[0 if s == 0 else 1] for s in range(S)], dim=0)
+        return torch.cat([sp, pt], dim=1).reshape(S * (n_special + hw), C).contiguous()
+
+    def cast_act(self, x):
+        return self._r(x.clone())
