@@ -4,5 +4,6 @@ The directory name carries a hyphen (it mirrors the reference repo's name); impo
 (the tiny shim package of that name at the repo root redirects here).
 """
 from .config import FWConfig, wan21_14b, plumbing  # noqa: F401
+from .install import install, uninstall  # noqa: F401
 
-__all__ = ["FWConfig", "wan21_14b", "plumbing"]
+__all__ = ["FWConfig", "wan21_14b", "plumbing", "install", "uninstall"]

@@ -1,0 +1,78 @@
+"""Drop-in boundary B1: rebind FantasyWorldFusionModel.joint_forward on a live reference model.
+
+    from fantasy_world_amd import install
+    sampler = FantasyWorldSampler(...)          # the reference's own inference_wan21.py object
+    install(sampler.model)                      # weights are read from the live module tree (after .to(bf16), LoRA
+                                                # merges, load_state_dict) and packed for the HIP kernels
+    sampler.generate_video(...)                 # unchanged reference code now steps through libfw_mi355x.so
+
+The replacement keeps the reference signature and return convention
+(FantasyWorld/fusion/model_wan21.py:104-116,217-224): (noise_pred[B,16,F,H,W] in x.dtype, prediction dict | None).
+The once-per-generation geometry heads stay the reference's own modules: on the last step the engine
+hands the aggregated tokens of layers 7/11/17/23 to vggt._head_predction (vggt/models/vggt.py:134-154).
+"""
+import types
+
+import torch
+
+from .config import FWConfig
+from .engine import FusionEngine
+
+
+def config_from_model(model) -> FWConfig:
+    """Read the shape description off the live reference module tree."""
+    dit = model.pipe.dit
+    blocks = list(dit.blocks)
+    n_layers = len(blocks)
+    first = model.IRGBlock[0].x_dit if len(model.IRGBlock) else blocks[0]
+    first_dit = next((b for b in blocks if hasattr(b, "ffn")), first)
+    cfg = FWConfig(
+        dim=dit.dim, in_dim=dit.patch_embedding.in_channels, ffn_dim=first_dit.ffn_dim,
+        out_dim=dit.head.head.out_features // 4, text_dim=dit.text_embedding[0].in_features, freq_dim=dit.freq_dim,
+        eps=first_dit.norm1.eps, num_heads=first_dit.num_heads, num_layers=n_layers,
+        has_image_input=dit.has_image_input, start_index=model.start_index,
+        cross_attention_list=list(model.cross_attention_list), bicross_dim=model.bicross_dim,
+        bicross_heads=model.bicross_num_heads, vggt_dim=model.vggt.embed_dim,
+        camera_adapter=bool(getattr(model, "camera_control", False)),
+    )
+    return cfg
+
+
+def install(model, ops=None, device=None):
+    """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
+    tests may inject another op set to exercise this boundary on CPU."""
+    if ops is None:
+        from .hip_ops import HipOps
+        ops = HipOps(device or "cuda")
+    cfg = config_from_model(model)
+    params = dict(model.named_parameters())
+    engine = FusionEngine(cfg, params.__getitem__, ops)
+
+    def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
+                      camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,
+                      return_prediction=False, **kwargs):
+        out, outputs = engine.joint_forward(x, timestep, context, clip_feature=clip_feature, y=y,
+                                            plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
+                                            uncond=uncond, return_prediction=return_prediction,
+                                            camera_token=camera_token)
+        if not return_prediction:
+            return out, None
+        n = cfg.n_irg
+        output_list = [outputs.get(i) for i in range(n)]
+        f, h, w = x.shape[2], x.shape[3] // 2, x.shape[4] // 2
+        # dpt_head only reads the shape of `images` ([B,S,h,w,C], dpt_head.py:141,215)
+        patch_token = torch.empty(1, f, h, w, cfg.vggt_dim, dtype=out.dtype, device=out.device)
+        prediction = self.vggt._head_predction(patch_token, self.vggt.aggregator.patch_start_idx, output_list)
+        return out, prediction
+
+    model._fw_reference_joint_forward = model.joint_forward
+    model.joint_forward = types.MethodType(joint_forward, model)
+    model._fw_engine = engine
+    return engine
+
+
+def uninstall(model):
+    if hasattr(model, "_fw_reference_joint_forward"):
+        model.joint_forward = model._fw_reference_joint_forward
+        del model._fw_reference_joint_forward
+        del model._fw_engine

@@ -1,0 +1,290 @@
+"""-m gpu: every C-ABI kernel against the plain-PyTorch fp32 statement of the same op (oracle/ref_ops.py), on identical
+bf16-rounded inputs.  Tolerances (relative L2 over the whole output, stated per test):
+  * fp32-accumulate GEMM / attention writing bf16: 4e-3 (one bf16 rounding of the output = 2^-9 ~ 2e-3 per element,
+    plus P rounded to bf16 inside attention); writing fp32: 1e-3 (north-star op-level target)
+  * element-wise/normalisation kernels writing bf16: 4e-3; fp32 outputs: 1e-5.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from fantasy_world_amd.hip_ops import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_ops import TorchRefOps
+    return TorchRefOps()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+
+# --------------------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(300, 200, 128), (1, 5120, 256), (257, 1280, 1280), (1000, 448, 2048), (513, 64, 5120),
+               (128, 128, 64), (129, 130, 192), (2048, 1152, 1024), (777, 3072, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain_bf16_out(ops, ref, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    want = ref.linear(x, ref.pack_linear(w, b))
+    got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b))
+    assert got.dtype == torch.bfloat16 and got.shape == (M, N)
+    assert rel_l2(got.float(), want) < 4e-3
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu_tanh", "gelu_erf", "silu"])
+def test_gemm_activations(ops, ref, act):
+    M, N, K = 333, 384, 256
+    x, w, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6, scale=0.1)
+    want = ref.linear(x, ref.pack_linear(w, b), act=act)
+    got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), act=act, out_f32=True)
+    assert rel_l2(got, want) < 1e-3
+
+
+@pytest.mark.parametrize("res_dtype", ["f32", "bf16"])
+def test_gemm_affine_residual_epilogue(ops, ref, res_dtype):
+    """y = res + (acc+bias)*g1 + g0: gates (DIT21:246-251), LayerScale, VGGT post-MLP modulation (VB:78-81)."""
+    M, N, K = 515, 1024, 4096
+    x, w, b = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=K ** -0.5), rnd(N, seed=9, scale=0.1)
+    g1, g0 = rnd(N, seed=10), rnd(N, seed=11)
+    res = rnd(M, N, seed=12) if res_dtype == "bf16" else torch.randn(M, N, generator=torch.Generator().manual_seed(12))
+    want = ref.linear(x, ref.pack_linear(w, b), g1=g1, g0=g0, res=res, out_f32=True)
+    r = res.cuda().to(torch.bfloat16 if res_dtype == "bf16" else torch.float32)
+    if res_dtype == "f32":
+        got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), g1=g1.cuda(), g0=g0.cuda(), res=r, out_f32=True, out=r)
+        assert got.data_ptr() == r.data_ptr()          # in place on the fp32 residual stream
+        assert rel_l2(got, want) < 1e-3
+    else:
+        got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), g1=g1.cuda(), g0=g0.cuda(), res=r, out=r)
+        assert rel_l2(got.float(), want) < 4e-3
+
+
+def test_gemm_strided_views(ops, ref):
+    """A and C may be column slices of wider buffers (fused q|k|v, k|v projections)."""
+    M, K, N = 200, 128, 256
+    big = rnd(M, 3 * K, seed=13)
+    w, b = rnd(N, K, seed=14, scale=K ** -0.5), rnd(N, seed=15, scale=0.1)
+    want = ref.linear(big[:, K:2 * K], ref.pack_linear(w, b), out_f32=True)
+    outbuf = torch.zeros(M, 2 * N, dtype=torch.float32, device="cuda")
+    ops.linear(bf(big).cuda()[:, K:2 * K], ops.pack_linear(w, b), out_f32=True, out=outbuf[:, N:])
+    assert rel_l2(outbuf[:, N:], want) < 1e-3
+    assert outbuf[:, :N].abs().max().item() == 0.0
+
+
+def test_gemm_rejects_bad_k(ops):
+    x = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
+    from fantasy_world_amd.hip_ops import Linear
+    lin = Linear(torch.zeros(8, 100, dtype=torch.bfloat16, device="cuda"), None)
+    with pytest.raises(RuntimeError):
+        ops.linear(x, lin)
+
+
+def test_gemv_f32(ops, ref):
+    K, N = 256, 5120
+    x = torch.randn(K, generator=torch.Generator().manual_seed(1))
+    w, b = torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5, torch.randn(N) * 0.1
+    for silu_in, act in [(False, "silu"), (True, None)]:
+        want = ref.linear_f32(x, ref.pack_linear_f32(w, b), silu_in=silu_in, act=act)
+        got = ops.linear_f32(x.cuda(), ops.pack_linear_f32(w, b), silu_in=silu_in, act=act)
+        assert rel_l2(got, want) < 1e-5
+
+
+# --------------------------------------------------------------------------------------------------------- attention
+ATTN_CASES = [  # heads, hd, batch, Lq, Lk
+    (3, 128, 1, 300, 333), (2, 128, 1, 64, 64), (5, 128, 1, 1000, 257), (2, 128, 1, 257, 512),
+    (4, 96, 1, 290, 305), (12, 96, 1, 48, 63), (3, 64, 1, 500, 129), (16, 64, 3, 133, 133), (2, 64, 2, 31, 1),
+]
+
+
+@pytest.mark.parametrize("heads,hd,batch,Lq,Lk", ATTN_CASES)
+def test_attention_matches_softmax_reference(ops, ref, heads, hd, batch, Lq, Lk):
+    q, k, v = rnd(batch * Lq, heads * hd, seed=1), rnd(batch * Lk, heads * hd, seed=2), rnd(batch * Lk, heads * hd, seed=3)
+    want = ref.attention(q, k, v, heads, hd, batch=batch)
+    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, batch=batch)
+    assert rel_l2(got.float(), want) < 4e-3
+
+
+def test_attention_strided_qkv_and_accumulate(ops, ref):
+    """q/k/v as column slices of one fused buffer; second call accumulates (cross-attn text + image, DIT21:197-200)."""
+    heads, hd, L, Lc = 4, 128, 200, 77
+    D = heads * hd
+    qkv = rnd(L, 3 * D, seed=4)
+    ctx = rnd(Lc, 2 * D, seed=5)
+    want = ref.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], heads, hd)
+    want2 = want + ref.attention(qkv[:, :D], ctx[:, :D], ctx[:, D:], heads, hd)
+    g = bf(qkv).cuda()
+    c = bf(ctx).cuda()
+    got = ops.attention(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], heads, hd)
+    assert rel_l2(got.float(), want) < 4e-3
+    ops.attention(g[:, :D], c[:, :D], c[:, D:], heads, hd, out=got, accumulate=True)
+    assert rel_l2(got.float(), want2) < 5e-3
+
+
+def test_attention_large_score_spike(ops, ref):
+    """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence."""
+    heads, hd, Lq, Lk = 1, 128, 64, 640
+    q, k, v = rnd(Lq, hd, seed=6), rnd(Lk, hd, seed=7), rnd(Lk, hd, seed=8)
+    k[600] = q[5] * 3.0         # row 5's max jumps at tile 9
+    k[10] = q[9] * 4.0          # row 9's max is set in tile 0 and never changes
+    k = k.to(torch.bfloat16).float()
+    want = ref.attention(q, k, v, heads, hd)
+    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd)
+    assert rel_l2(got.float(), want) < 4e-3
+    assert torch.isfinite(got.float()).all()
+
+
+def test_attention_full_length_properties(ops):
+    """BASELINE config-2 size (L = 32760, hd 128): rows of softmax sum to 1 => V = const gives O = const, and
+    sampled query rows match an fp32 evaluation of the same rows."""
+    heads, hd, L = 2, 128, 32760
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    k = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    v = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    ones = torch.full_like(v, 0.5)
+    o1 = ops.attention(q, k, ones, heads, hd)
+    assert (o1.float() - 0.5).abs().max().item() < 4e-3
+    o = ops.attention(q, k, v, heads, hd)
+    rows = torch.tensor([0, 1, 255, 256, 9999, 16383, 32503, 32759], device="cuda")
+    for h in range(heads):
+        sl = slice(h * hd, (h + 1) * hd)
+        s = (q[rows][:, sl].float() @ k[:, sl].float().t()) / math.sqrt(hd)
+        want = torch.softmax(s, dim=-1) @ v[:, sl].float()
+        assert rel_l2(o[rows][:, sl].float(), want) < 6e-3
+
+
+def test_attention_rejects_bad_head_dim(ops):
+    q = torch.zeros(8, 80, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.attention(q, q, q, 1, 80)
+
+
+# --------------------------------------------------------------------------------------------------------- norms / rope
+@pytest.mark.parametrize("C,rows,affine,mod,xdt", [(5120, 70, False, True, "f32"), (5120, 33, True, False, "f32"),
+                                                   (1024, 129, True, True, "f32"), (1280, 257, True, False, "bf16"),
+                                                   (5120, 5, True, False, "bf16")])
+def test_layernorm_mod(ops, ref, C, rows, affine, mod, xdt):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, C, generator=g) * 3 + 0.5
+    if xdt == "bf16":
+        x = x.to(torch.bfloat16).float()
+    w = (1 + 0.1 * torch.randn(C, generator=g)) if affine else None
+    b = 0.1 * torch.randn(C, generator=g) if affine else None
+    sc = torch.randn(C, generator=g) if mod else None
+    sh = torch.randn(C, generator=g) if mod else None
+    eps = 1e-6 if not affine else 1e-5
+    want = ref.layernorm(x, w, b, sc, sh, eps)
+    cu = lambda t: None if t is None else t.cuda()
+    xin = x.cuda().to(torch.bfloat16) if xdt == "bf16" else x.cuda()
+    got = ops.layernorm(xin, cu(w), cu(b), cu(sc), cu(sh), eps)
+    assert rel_l2(got.float(), want) < 4e-3
+
+
+def test_qk_prep_rms_full_rope3d(ops, ref):
+    """DiT q/k: RMSNorm over the full 5120 width (DIT21:170-171) + interleaved 3-D RoPE (DIT21:97-102)."""
+    from fantasy_world_amd import rope
+    heads, hd = 40, 128
+    f, h, w = 2, 3, 5
+    L = f * h * w
+    tab = rope.rope3d_table(hd, f, h, w)
+    x = rnd(L, 3 * heads * hd, seed=9)
+    nw = 1 + 0.1 * torch.randn(heads * hd, generator=torch.Generator().manual_seed(1))
+    xr = x.clone()
+    ref.qk_prep(xr[:, heads * hd:2 * heads * hd], heads, hd, "rms_full", nw, None, 1e-6, "interleaved", tab)
+    xg = bf(x).cuda()
+    ops.qk_prep(xg[:, heads * hd:2 * heads * hd], heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab.cuda())
+    assert rel_l2(xg.float(), xr) < 4e-3
+    assert torch.equal(xg[:, :heads * hd].float().cpu(), x[:, :heads * hd])        # neighbours untouched
+
+
+def test_qk_prep_ln_head_rope2d(ops, ref):
+    """VGGT q/k: per-head LayerNorm(64) (VA:43-44) + 2-D rotate-half RoPE base 100 (VR:154-188), table row = row % P."""
+    from fantasy_world_amd import rope
+    heads, hd, S, h, w = 16, 64, 3, 4, 5
+    P = 5 + h * w
+    tab = rope.rope2d_table(hd, h, w, 5)
+    x = rnd(S * P, heads * hd, seed=10)
+    g = torch.Generator().manual_seed(2)
+    nw, nb = 1 + 0.1 * torch.randn(hd, generator=g), 0.1 * torch.randn(hd, generator=g)
+    xr = x.clone()
+    ref.qk_prep(xr, heads, hd, "ln_head", nw, nb, 1e-5, "half2d", tab)
+    xg = bf(x).cuda()
+    ops.qk_prep(xg, heads, hd, "ln_head", nw.cuda(), nb.cuda(), 1e-5, "half2d", tab.cuda())
+    assert rel_l2(xg.float(), xr) < 4e-3
+
+
+def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref):
+    """bicross k: no norm, RoPE-3D hd=96 with 5 un-rotated special tokens per frame (DIT21:105-132)."""
+    from fantasy_world_amd import rope
+    heads, hd, f, h, w = 12, 96, 2, 3, 4
+    tab = rope.rope3d_table_with_extra(hd, f, h, w, 5)
+    rows = f * (5 + h * w)
+    x = rnd(rows, heads * hd, seed=11)
+    xr = x.clone()
+    ref.qk_prep(xr, heads, hd, None, None, None, 1e-6, "interleaved", tab)
+    xg = bf(x).cuda()
+    ops.qk_prep(xg, heads, hd, None, None, None, 1e-6, "interleaved", tab.cuda())
+    assert rel_l2(xg.float(), xr) < 4e-3
+    assert torch.equal(xg[:5].float().cpu(), x[:5])                                # identity rows bit-exact
+
+
+def test_qk_prep_rms_no_rope(ops, ref):
+    heads, hd = 40, 128
+    x = rnd(50, heads * hd, seed=12)
+    nw = 1 + 0.1 * torch.randn(heads * hd, generator=torch.Generator().manual_seed(1))
+    xr = x.clone()
+    ref.qk_prep(xr, heads, hd, "rms_full", nw, None, 1e-6)
+    xg = bf(x).cuda()
+    ops.qk_prep(xg, heads, hd, "rms_full", nw.cuda(), None, 1e-6)
+    assert rel_l2(xg.float(), xr) < 4e-3
+
+
+# --------------------------------------------------------------------------------------------------------- layout glue
+def test_sinusoid_bf16_timestep(ops, ref):
+    """The sampler hands joint_forward a bf16 timestep (M21:292-293): 999.x -> 1000."""
+    for t in (torch.tensor([937.5]), torch.tensor([999.3]).to(torch.bfloat16), torch.tensor([0.0])):
+        want = ref.sinusoid(t.float() if t.dtype == torch.bfloat16 else t, 256)
+        got = ops.sinusoid(t.cuda(), 256)
+        assert (got.cpu() - want).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patchify_unpatchify(ops, ref, dt):
+    F_, H2, W2 = 3, 8, 12
+    x, y = rnd(1, 16, F_, H2, W2, seed=1), rnd(1, 20, F_, H2, W2, seed=2)
+    want = ref.patchify(x, y, 192)
+    got = ops.patchify(x.cuda().to(dt), y.cuda().to(dt), 192)
+    assert torch.equal(got.float().cpu(), want)
+    hd = torch.randn(F_ * 4 * 6, 64)
+    want_u = ref.unpatchify(hd, F_, 4, 6, torch.float32)
+    got_u = ops.unpatchify(hd.cuda(), F_, 4, 6, dt)
+    assert got_u.shape == (1, 16, F_, 8, 12)
+    assert torch.equal(got_u.float().cpu(), want_u.to(dt).float())
+
+
+def test_assemble_tokens_and_cast(ops, ref):
+    S, hw, C = 4, 7, 1024
+    patch = rnd(S * hw, C, seed=3)
+    special = torch.randn(2, 5, C)
+    want = ref.assemble_tokens(patch, special, S, hw)
+    got = ops.assemble_tokens(bf(patch).cuda(), special.cuda(), S, hw)
+    assert torch.equal(got.cpu(), want)
+    x = torch.randn(37, 5120)
+    assert torch.equal(ops.cast_act(x.cuda()).cpu(), x.to(torch.bfloat16))

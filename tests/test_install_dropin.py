@@ -1,0 +1,35 @@
+"""Drop-in boundary: install() on the REAL reference model (build container only; skipped where /root/reference is
+absent).  The reference object keeps its signature and returns; only the arithmetic provider changes."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.environ.get("FW_REFERENCE_ROOT", "/root/reference")),
+                                reason="reference tree not mounted")
+
+
+def test_install_rebinds_joint_forward_on_reference_model(case_l2):
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install, uninstall
+    case = case_l2
+    model = ref_harness.build_reference_wan21(case.cfg, weights=case.weights)
+    ins = case.inputs
+    kw = dict(timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
+              use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+              plucker_context_lens=ins["plucker_context_lens"], return_prediction=False)
+    with torch.no_grad():
+        want, p0 = model.joint_forward(ins["x"], **kw)
+    eng = install(model, ops=TorchRefOps())
+    assert eng.cfg.ffn_dim == case.cfg.ffn_dim and eng.cfg.cross_attention_list == case.cfg.cross_attention_list
+    got, p1 = model.joint_forward(ins["x"], **kw)           # same call site, same kwargs as M21:295-305
+    assert p0 is None and p1 is None
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert rel_l2(got, want) < 2e-5
+    uninstall(model)
+    with torch.no_grad():
+        again, _ = model.joint_forward(ins["x"], **kw)
+    assert torch.equal(again, want)

@@ -1,0 +1,80 @@
+"""-m gpu: the whole HIP joint_forward (through the C ABI) against the reference goldens and the CPU oracle.
+
+Tolerance: activations between kernels are bf16 (the reference's own inference dtype), accumulation / statistics /
+residual streams fp32.  The reference's own bf16-vs-fp32 deviation is 3.2e-3 after ONE DiT block;
+emulating exactly our rounding points on CPU gives 2.6e-3 end-to-end on this 2-block model
+(tests/test_engine_cpu.py::test_engine_bf16_emulation_yardstick).  The end-to-end bound is therefore 8e-3 relative L2
+against the fp32 reference; the <= 1e-3 north-star bound is enforced per kernel in tests/test_hip_ops.py.
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+E2E_TOL = 8e-3
+
+
+def _run_hip(case, **over):
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    ops = HipOps("cuda:0")
+    eng = FusionEngine(case.cfg, case.weights.__getitem__, ops)
+    ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
+    ins.update(over)
+    col = {}
+    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"],
+                                  y=ins["y"], plucker_fea=ins["plucker_fea"],
+                                  plucker_context_lens=ins["plucker_context_lens"], uncond=case.uncond, collect=col)
+    torch.cuda.synchronize()
+    assert pred is None
+    col["noise_pred"] = out
+    return col, eng
+
+
+@pytest.mark.parametrize("case_name", ["case_l2", "case_l3"])
+def test_hip_joint_forward_matches_reference_golden(case_name, request):
+    case = request.getfixturevalue(case_name)
+    col, _ = _run_hip(case)
+    errs = {k: rel_l2(col[k].float().reshape(case.golden[k].shape), case.golden[k])
+            for k in ("x_after_pcb", "x_final", "tokens_final", "noise_pred")}
+    print(case.name, {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < E2E_TOL, (case.name, k, v)
+    assert torch.isfinite(col["noise_pred"].float()).all()
+
+
+def test_hip_joint_forward_bf16_inputs_and_determinism(case_l2):
+    """The inference scripts feed bf16 latents/context and a bf16 timestep (I21:310, M21:292-293); the output comes back
+    in the latents' dtype; two runs are bit-identical (no atomics on the path)."""
+    case = case_l2
+    ins = case.inputs
+    over = dict(x=ins["x"].cuda().bfloat16(), y=ins["y"].cuda().bfloat16(), context=ins["context"].cuda().bfloat16(),
+                clip_feature=ins["clip_feature"].cuda().bfloat16(), plucker_fea=ins["plucker_fea"].cuda().bfloat16(),
+                timestep=ins["timestep"].cuda().bfloat16())
+    a, _ = _run_hip(case, **over)
+    b, _ = _run_hip(case, **over)
+    assert a["noise_pred"].dtype == torch.bfloat16
+    assert torch.equal(a["noise_pred"], b["noise_pred"])
+    assert rel_l2(a["noise_pred"].float(), case.golden["noise_pred"]) < 1.2e-2   # + bf16 rounding of the output
+
+
+def test_hip_matches_cpu_oracle_on_negative_prompt_and_uncond(case_l2):
+    """Second context draw (the CFG negative pass) and uncond=True (bicross skipped, IRG:70-72) vs the CPU oracle."""
+    from oracle import fw_oracle
+    case = case_l2
+    ins = case.inputs
+    for uncond in (False, True):
+        want = fw_oracle.joint_forward(case.weights, case.cfg, ins["x"], ins["timestep"], ins["context_neg"],
+                                       ins["clip_feature"], ins["y"], ins["plucker_fea"], ins["plucker_context_lens"],
+                                       uncond=uncond)
+        from fantasy_world_amd.engine import FusionEngine
+        from fantasy_world_amd.hip_ops import HipOps
+        eng = FusionEngine(case.cfg, case.weights.__getitem__, HipOps("cuda:0"))
+        d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ins.items()}
+        got, _ = eng.joint_forward(d["x"], d["timestep"], d["context_neg"], clip_feature=d["clip_feature"], y=d["y"],
+                                   plucker_fea=d["plucker_fea"], plucker_context_lens=d["plucker_context_lens"],
+                                   uncond=uncond)
+        assert rel_l2(got.float(), want) < E2E_TOL, uncond
+        del eng
