@@ -116,6 +116,19 @@ class HipOps:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HipOps only runs on a HIP device")
+        self._timing = None
+
+    # ---- live kernel timing (bench.py roofline): HIP events on the launch stream around selected attention launches
+    def start_kernel_timing(self, tag, predicate):
+        self._timing = dict(tag=tag, pred=predicate, events=[])
+
+    def stop_kernel_timing(self):
+        """-> (average launch duration in ms, number of launches timed); call after a device synchronize."""
+        t, self._timing = self._timing, None
+        if not t or not t["events"]:
+            return 0.0, 0
+        ms = [a.elapsed_time(b) for a, b in t["events"]]
+        return sum(ms) / len(ms), len(ms)
 
     # ---- memory plumbing ------------------------------------------------------------------------------------
     def _stream(self):
@@ -206,10 +219,17 @@ class HipOps:
         assert lk2 == Lk
         if out is None:
             out = torch.empty(batch * Lq, heads * hd, dtype=torch.bfloat16, device=self.device)
+        ev = None
+        if self._timing is not None and self._timing["pred"](dict(hd=hd, Lq=Lq, Lk=Lk, heads=heads, batch=batch)):
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(self.device))
         _check(self.lib.fw_attention_bf16(
             q.data_ptr(), q.stride(0), Lq * q.stride(0), k.data_ptr(), k.stride(0), Lk * k.stride(0),
             vt.data_ptr(), vt.shape[-1], out.data_ptr(), out.stride(0), Lq * out.stride(0),
             batch, heads, hd, Lq, Lk, 1.0 / math.sqrt(hd), int(accumulate), self._stream()), "fw_attention_bf16")
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(self.device))
+            self._timing["events"].append(ev)
         return out
 
     # ---- embeddings / layout ------------------------------------------------------------------------------------
