@@ -12,8 +12,9 @@
 // the two MFMAs and every LDS fragment read is a conflict-free ds_read_b128:
 //   K tile  : 64 rows x 256 B (row stride fixed at 256 B, hd/8 valid 16-B chunks), chunk ^= row&15
 //   Vt tile : hd rows x 128 B, chunk ^= (row>>1)&7
-// Both tiles are filled with global_load_lds_dwordx4 (swizzle applied on the source address), double buffered,
-// one barrier per tile.  Work-groups are ordered so that one XCD works on one head at a time (K/V stay in its L2).
+// Both tiles are filled with global_load_lds_dwordx4 (swizzle applied on the source address) into 2-slot rings, one
+// barrier per tile.  The loop is software pipelined: K runs one tile ahead of V, and the QK^T MFMAs of tile t+1 are
+// issued between the row-max and the exponentials of tile t, so matrix and vector work of one wave overlap.  Work-groups are ordered so that one XCD works on one head at a time (K/V stay in its L2).
 #include "fw_common.h"
 
 namespace {
@@ -39,8 +40,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
     constexpr int DB = HD / 32;          // 32-row blocks of O^T
     constexpr int NCH = HD / 8;          // valid 16-B chunks per K row
     constexpr int VT_TILE_BYTES = HD * 128;
-    constexpr int STAGE = K_TILE_BYTES + VT_TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,17 +101,24 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
         vg[i] = Vp + (int64_t)min(d, HD - 1) * p.lkp + chunk * 8;
     }
 
-    auto stage = [&](int s, int t) {
-        char* k_lds = smem + s * STAGE;
-        char* v_lds = k_lds + K_TILE_BYTES;
+    // K ring: 2 slots of K_TILE_BYTES; Vt ring: 2 slots of VT_TILE_BYTES
+    auto stage_k = [&](int slot, int t) {
+        char* k_lds = smem + slot * K_TILE_BYTES;
+        const int k0 = t * KVB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (kvalid[i]) {
+                const int kr = min(k0 + krow[i], p.Lk - 1);
+                FW_GLDS16(kg[i] + (int64_t)kr * p.ldk, k_lds + (wave + 8 * i) * 1024);
+            }
+        }
+    };
+    auto stage_v = [&](int slot, int t) {
+        char* v_lds = smem + 2 * K_TILE_BYTES + slot * VT_TILE_BYTES;
         const int k0 = t * KVB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int pc = wave + 8 * i;
-            if (kvalid[i]) {
-                const int kr = min(k0 + krow[i], p.Lk - 1);
-                FW_GLDS16(kg[i] + (int64_t)kr * p.ldk, k_lds + pc * 1024);
-            }
             if (pc < HD / 8) FW_GLDS16(vg[i] + k0, v_lds + pc * 1024);
         }
     };
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
     for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
     int vcoff[4];                     // Vt: chunk (2s+hi) ^ ((fi>>1)&7)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) vcoff[s] = K_TILE_BYTES + fi * 128 + (((2 * s + hi) ^ ((fi >> 1) & 7)) << 4);
+    for (int s = 0; s < 4; ++s) vcoff[s] = 2 * K_TILE_BYTES + fi * 128 + (((2 * s + hi) ^ ((fi >> 1) & 7)) << 4);
 
     f32x16_t o[DB];
 #pragma unroll
@@ -132,16 +139,12 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
     float m_run = -1.0e30f;    // running max of raw scores (finite sentinel: no inf-inf)
     float l_run = 0.f;         // this half-wave's partial row sum
     const float c = p.scale_log2;
-
     const int nt = (p.Lk + KVB - 1) / KVB;
-    stage(0, 0);
-    __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        const char* base = smem + (t & 1) * STAGE;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
 
-        // ---- S^T = K Q^T : two 32-key blocks ----------------------------------------------------------------
-        f32x16_t s0, s1;
+    // S^T = K Q^T for the K tile in ring slot `slot` (two 32-key blocks), masked if it is the ragged last tile
+    auto qk = [&](f32x16_t& s0, f32x16_t& s1, int slot, int t) {
+        const char* base = smem + slot * K_TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
@@ -151,8 +154,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0f, qf[ks], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1f, qf[ks], s1, 0, 0, 0);
         }
-        // ---- mask the ragged last tile (keys >= Lk) ----------------------------------------------------------
-        if (t == nt - 1 && (p.Lk & (KVB - 1))) {
+        if (ragged && t == nt - 1) {
             const int kbase = t * KVB + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -161,11 +163,20 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
                 if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
             }
         }
-        // ---- online softmax (per query = per lane column) ---------------------------------------------------
-        float mx = fmaxf(s0[0], s1[0]);
+    };
+
+    // One KV tile: online softmax of the scores already in (c0,c1), QK^T of the NEXT tile into (n0,n1) issued
+    // between the max and the exponentials (independent MFMA work that overlaps the softmax VALU), then P V.
+    auto tile = [&](f32x16_t& c0, f32x16_t& c1, f32x16_t& n0, f32x16_t& n1, int t) {
+        if (t + 2 < nt) stage_k(t & 1, t + 2);
+        if (t + 1 < nt) stage_v((t + 1) & 1, t + 1);
+        float mx = fmaxf(c0[0], c1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(c0[r], c1[r]));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new > m_run)) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -176,33 +187,45 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
             m_run = m_new;
         }
+        if (t + 1 < nt) qk(n0, n1, (t + 1) & 1, t + 1);
         const float mc = m_run * c;
-        uint32_t pw[16];   // P^T packed to bf16: words 0..7 from block 0, 8..15 from block 1
+        uint32_t pw[16];   // P^T packed to bf16: words 0..7 from key block 0, 8..15 from key block 1
         float ls = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-            const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
-            const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-            const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+            const float a0 = __builtin_amdgcn_exp2f(fmaf(c0[r], c, -mc));
+            const float a1 = __builtin_amdgcn_exp2f(fmaf(c0[r + 1], c, -mc));
+            const float b0 = __builtin_amdgcn_exp2f(fmaf(c1[r], c, -mc));
+            const float b1 = __builtin_amdgcn_exp2f(fmaf(c1[r + 1], c, -mc));
             ls += (a0 + a1) + (b0 + b1);
             pw[r >> 1] = pack_bf16x2(a0, a1);
             pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
         }
         l_run += ls;
-
-        // ---- O^T += Vt P^T : 4 k-steps of 16 keys -------------------------------------------------------------
+        const char* vbase = smem + (t & 1) * VT_TILE_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             u32x4_t pv4 = {pw[4 * s], pw[4 * s + 1], pw[4 * s + 2], pw[4 * s + 3]};
             bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
 #pragma unroll
             for (int d = 0; d < DB; ++d) {
-                bf16x8_t vf = *(const bf16x8_t*)(base + d * 32 * 128 + vcoff[s]);
+                bf16x8_t vf = *(const bf16x8_t*)(vbase + d * 32 * 128 + vcoff[s]);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
             }
         }
-        __syncthreads();
+        __syncthreads();   // K(t+2), V(t+1) landed (vmcnt(0)); every wave is done with K(t+1)'s slot reads and V(t)
+    };
+
+    f32x16_t sa0, sa1, sb0, sb1;
+    stage_k(0, 0);
+    stage_v(0, 0);
+    if (nt > 1) stage_k(1, 1);
+    __syncthreads();
+    qk(sa0, sa1, 0, 0);
+    __syncthreads();           // K slot 0 may now be refilled
+    for (int t = 0; t < nt; t += 2) {
+        tile(sa0, sa1, sb0, sb1, t);
+        if (t + 1 < nt) tile(sb0, sb1, sa0, sa1, t + 1);
     }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l --------------------------------------------------------------------

@@ -20,14 +20,17 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as
 
 // round-to-nearest-even fp32 -> bf16 bits (NaN preserved as quiet NaN)
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    return __builtin_bit_cast(uint16_t, (__bf16)f);    // hardware convert on gfx950
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// two fp32 -> packed bf16x2 with the gfx950 hardware convert (v_cvt_pk_bf16_f32, round-to-nearest-even)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+    bf16x2_t v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float fw_gelu_tanh(float x) {
