@@ -9,6 +9,7 @@
 // Work-group ids are remapped so each XCD (private L2) owns a contiguous range of tiles, grouped 8 M-tiles
 // deep so concurrently resident tiles share A bands and W panels in L2.
 #include "fw_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -148,6 +149,225 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 accumulators of 32x32.  One work-group per CU, so the
+// two waves that share a SIMD belong to the SAME work-group; to keep the matrix pipe fed they are run half a phase
+// apart: waves 0-3 (group A) and 4-7 (group B) execute the same sequence of  [LOAD fragments | barrier | 16 MFMA |
+// barrier]  phases, but group B takes one extra barrier at the start (and group A one at the end), so that while one
+// wave of a SIMD is in its MFMA segment its partner is in its LDS-read segment.  A k-slab is consumed in two phases
+// (wave rows 0-63, then 64-127; the B fragments are read once per slab).  The next slab is streamed with
+// global_load_lds during the phases in which its LDS stage is provably idle, and waited for (vmcnt(0)) one barrier
+// before its first read:
+//     global slot:      4t      4t+1      4t+2      4t+3      4t+4
+//     group A:        LOAD(t,0) MFMA(t,0) LOAD(t,1) MFMA(t,1) LOAD(t+1,0)
+//     group B:        MFMA(..)  LOAD(t,0) MFMA(t,0) LOAD(t,1) MFMA(t,1)
+//     slab t+1 DMA:   A: 1/2    B: all    A: 1/2    wait      first read (A)   -- last read of slab t-1 completes
+//                                                                                  before the barrier ending slot 4t-1
+// Barriers are raw s_barrier (inline asm): a __syncthreads() would drain the DMA queue at every barrier.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TM = 256, TN = 256;
+constexpr int STAGE2 = (TM + TN) * BK * 2;   // 64 KiB
+
+#define FW_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FW_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs p) {
+    constexpr bool DMA_IN_LOAD = (VAR & 1) != 0, DRAIN_LDS = (VAR & 2) != 0, PRIO = (VAR & 4) != 0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = (VAR & 8) ? (wave & 1) : (wave >> 2);
+    const int wn = (VAR & 8) ? (wave >> 1) : (wave & 3);
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // staging: wave w streams A pieces 4w..4w+3 and W pieces 4w..4w+3 of every slab (1 KiB = 8 rows x 128 B each).
+    // Uniform 64-bit tile base (SGPR) + per-lane 32-bit element offsets keep the address state at 8 VGPRs.
+    const uint16_t* abase = p.A + (int64_t)m0 * p.lda;
+    const uint16_t* wbase = p.W + (int64_t)n0 * p.ldw;
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        aoff[i] = min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8;
+        woff[i] = min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8;
+    }
+#define FW_STAGE_PIECE(S, KT, I)                                                                   \
+    do {                                                                                           \
+        FW_GLDS16(abase + (KT) * BK + aoff[I], smem + (S) * STAGE2 + (wave * 4 + (I)) * 1024);     \
+        FW_GLDS16(wbase + (KT) * BK + woff[I], smem + (S) * STAGE2 + TM * BK * 2 + (wave * 4 + (I)) * 1024); \
+    } while (0)
+#define FW_STAGE_FIRST(S, KT) do { FW_STAGE_PIECE(S, KT, 0); FW_STAGE_PIECE(S, KT, 1); } while (0)
+#define FW_STAGE_SECOND(S, KT) do { FW_STAGE_PIECE(S, KT, 2); FW_STAGE_PIECE(S, KT, 3); } while (0)
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + hi) ^ swz) << 4;
+    const int a_row_off = (grp * 128 + fi) * 128;                    // + rb*32*128, rb = 0..3
+    const int b_row_off = TM * BK * 2 + (wn * 64 + fi) * 128;        // + nb*32*128
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t afr[2][4], bfr[2][4];
+
+    const int nk = p.K / BK;
+    FW_STAGE_FIRST(0, 0);
+    FW_STAGE_SECOND(0, 0);
+    FW_WAIT_DMA();
+    FW_BARRIER();
+    if (grp == 1) FW_BARRIER();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * STAGE2;
+        const bool more = kt + 1 < nk;
+        const int ns = (kt + 1) & 1;
+        // ---------------- phase (kt, 0): B fragments + A rows 0..63 of the wave tile.
+        // DMA of slab kt+1 is issued only from LOAD segments (never in front of an MFMA burst): group A issues half in
+        // each of its two LOAD segments (slots 4t, 4t+2), group B all of it in LOAD(kt,0) (slot 4t+1).  Every LOAD
+        // segment drains its own ds_reads (lgkmcnt(0)) BEFORE the barrier, so when a barrier releases, no read of the
+        // previous slab is in flight and the stage may be overwritten from slot 4t on.
+        if (more) {
+            if (DMA_IN_LOAD) {
+                FW_STAGE_FIRST(ns, kt + 1);
+                if (grp == 1) FW_STAGE_SECOND(ns, kt + 1);
+            } else if (grp == 1) {
+                FW_STAGE_FIRST(ns, kt + 1);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bfr[0][ks] = *(const bf16x8_t*)(base + b_row_off + coff[ks]);
+            bfr[1][ks] = *(const bf16x8_t*)(base + b_row_off + 32 * 128 + coff[ks]);
+            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + coff[ks]);
+            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 32 * 128 + coff[ks]);
+        }
+        if (DRAIN_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FW_BARRIER();
+        if (!DMA_IN_LOAD && more) {
+            if (grp == 0) FW_STAGE_FIRST(ns, kt + 1);
+            else FW_STAGE_SECOND(ns, kt + 1);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[1][1], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        FW_BARRIER();
+        // ---------------- phase (kt, 1): A rows 64..127 of the wave tile
+        if (grp == 0 && more) FW_STAGE_SECOND(ns, kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + 64 * 128 + coff[ks]);
+            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 96 * 128 + coff[ks]);
+        }
+        if (DRAIN_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) FW_WAIT_DMA();          // group B: end of slot 4t+3
+        FW_BARRIER();
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[2][1], 0, 0, 0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[3][1], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) FW_WAIT_DMA();          // group A: end of slot 4t+3
+        FW_BARRIER();
+    }
+    if (grp == 0) FW_BARRIER();
+
+    // ---- epilogue through LDS: each wave transposes its 128x64 result in two 64-row passes through a private 16 KiB
+    // region (fp32, row stride 256 B), so that global traffic is row-contiguous 16-B (fp32) / 8-B (bf16) per lane:
+    // residual loads and output stores touch whole 128-B lines instead of 2-4 B per lane at a row stride.
+    // bias / activation / per-column affine are applied on the way in (column == lane in the accumulator layout).
+    {
+        char* reg = smem + wave * 16384;
+        float bias2[2], g12[2], g02[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + wn * 64 + nb * 32 + fi;
+            const bool ok = col < p.N;
+            bias2[nb] = (p.bias && ok) ? p.bias[col] : 0.f;
+            g12[nb] = (p.g1 && ok) ? p.g1[col] : 1.f;
+            g02[nb] = (p.g0 && ok) ? p.g0[col] : 0.f;
+        }
+        const int rl = lane >> 4;              // row inside a 4-row read group
+        const int c4 = (lane & 15) * 4;        // first of this lane's 4 columns
+        const int gcol = n0 + wn * 64 + c4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[2 * q + rb2][nb][r] + bias2[nb];
+                        v = fw_apply_act(v, p.act);
+                        v = v * g12[nb] + g02[nb];
+                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
+                    }
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row_l = it * 4 + rl;
+                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
+                const int row = m0 + grp * 128 + q * 64 + row_l;
+                if (row < p.M && gcol < p.N) {
+                    if (p.res_dtype == FW_DT_F32) {
+                        const f32x4_t rv = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+                        v += rv;
+                    } else if (p.res_dtype == FW_DT_BF16) {
+                        const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
+                        v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
+                    }
+                    if (p.out_dtype == FW_DT_F32) {
+                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                    } else {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // fp32 GEMV for the M=1 time-embedding MLPs: one wave per output feature.
 __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, float* __restrict__ out,
@@ -185,6 +405,35 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.out_dtype = out_dtype;
     p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.g1 = g1; p.g0 = g0;
     p.res = res; p.ldr = ldr; p.res_dtype = res ? res_dtype : FW_DT_NONE;
+    // tile choice: the 256x256 staggered kernel for the big token-major GEMMs, 128x128 otherwise.
+    // FW_GEMM_TILE=128|256 forces one (A/B measurements).
+    static const int forced = [] { const char* e = getenv("FW_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    bool big = (M >= 2048 && N >= 1024);
+    if (forced == 128) big = false;
+    if (forced == 256) big = true;
+    // the 256 kernel's epilogue moves 4 columns per lane: needs N, ldc, ldr % 4 == 0 and 16-B (fp32) / 8-B (bf16) bases
+    const uintptr_t cmask = (out_dtype == FW_DT_F32) ? 15 : 7;
+    const uintptr_t rmask = (res_dtype == FW_DT_F32) ? 15 : 7;
+    if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & cmask) || (res && ((ldr % 4) || (((uintptr_t)res) & rmask)))) big = false;
+    if (big) {
+        p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
+        const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+        if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
+        static const int var = [] { const char* e = getenv("FW_GEMM_VAR"); return e ? atoi(e) : 0; }();
+        hipStream_t st = (hipStream_t)stream;
+        switch (var) {
+            case 1: hipLaunchKernelGGL(gemm_bf16_256_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 2: hipLaunchKernelGGL(gemm_bf16_256_kernel<2>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 3: hipLaunchKernelGGL(gemm_bf16_256_kernel<3>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 4: hipLaunchKernelGGL(gemm_bf16_256_kernel<4>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 6: hipLaunchKernelGGL(gemm_bf16_256_kernel<6>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 7: hipLaunchKernelGGL(gemm_bf16_256_kernel<7>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 8: hipLaunchKernelGGL(gemm_bf16_256_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            case 12: hipLaunchKernelGGL(gemm_bf16_256_kernel<12>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            default: hipLaunchKernelGGL(gemm_bf16_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+        }
+        return (int)hipGetLastError();
+    }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
