@@ -74,6 +74,71 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const void* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast path: ONE WAVE per row (4 rows per 256-thread group), row held in registers, statistics by wave shuffles:
+// no LDS, no barriers, VPL independent 16-B loads in flight per lane.  C = 4 * 64 * k, k <= LNW_MAXV (C <= 5120).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LNW_MAXV = 20;
+
+template <bool XF32, int VPL>
+__global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __restrict__ xin, int64_t ldx,
+                                                                 uint16_t* __restrict__ y, int64_t ldy, int rows, int C,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4_t v[VPL];
+    if (XF32) {
+        const float* xr = (const float*)xin + (int64_t)row * ldx;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = *(const f32x4_t*)(xr + (lane + 64 * i) * 4);
+    } else {
+        const uint16_t* xr = (const uint16_t*)xin + (int64_t)row * ldx;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const u32x2_t raw = *(const u32x2_t*)(xr + (lane + 64 * i) * 4);
+            v[i][0] = __uint_as_float(raw[0] << 16); v[i][1] = __uint_as_float(raw[0] & 0xffff0000u);
+            v[i][2] = __uint_as_float(raw[1] << 16); v[i][3] = __uint_as_float(raw[1] & 0xffff0000u);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    uint16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c0 = (lane + 64 * i) * 4;
+        f32x4_t t = (v[i] - mean) * rstd;
+        if (w) { t = t * *(const f32x4_t*)(w + c0); if (b) t = t + *(const f32x4_t*)(b + c0); }
+        if (scale) t = t * (1.0f + *(const f32x4_t*)(scale + c0));
+        if (shift) t = t + *(const f32x4_t*)(shift + c0);
+        u32x2_t out = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+        *(u32x2_t*)(yr + c0) = out;
+    }
+}
+
+template <bool XF32>
+static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C,
+                           const float* w, const float* b, const float* scale, const float* shift, float eps) {
+    const dim3 grid((rows + 3) / 4), block(256);
+#define FW_LN_CASE(V) case V: hipLaunchKernelGGL((layernorm_mod_wave_kernel<XF32, V>), grid, block, 0, st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps); return true;
+    switch (C / 256) {
+        FW_LN_CASE(4) FW_LN_CASE(5) FW_LN_CASE(8) FW_LN_CASE(20)
+        default: return false;
+    }
+#undef FW_LN_CASE
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // q/k normalisation + rotary, in place on a bf16 [rows][heads*hd] slice.  One work-group per row; each thread
 // owns up to QK_MAXC chunks of 8 consecutive channels; the normalised row is parked in LDS (fp32) so the rotary
@@ -211,6 +276,126 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast path of qk_prep: ONE WAVE per row, chunk (8 channels, 16 B) index = lane + 64*i, statistics and the rotate-half
+// partner exchange by wave shuffles (head_dim 64: a head is 8 consecutive lanes, the partner chunk is lane ^ 2).
+// ------------------------------------------------------------------------------------------------------------
+template <int CPL, int NORM, int ROPE>
+__global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int heads, int hd,
+                                                           const float* __restrict__ nw, const float* __restrict__ nb, float eps,
+                                                           const float* __restrict__ tab, int tab_rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int width = heads * hd;
+    const int nch = width >> 3;
+    uint16_t* xr = x + (int64_t)row * ldx;
+    float v[CPL][8];
+    u32x4_t raw[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int ch = lane + 64 * i;
+        raw[i] = u32x4_t{0, 0, 0, 0};
+        if (ch < nch) raw[i] = *(const u32x4_t*)(xr + ch * 8);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[i][2 * j] = __uint_as_float(raw[i][j] << 16);
+            v[i][2 * j + 1] = __uint_as_float(raw[i][j] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+    if (NORM == FW_NORM_RMS_FULL) {
+        const float r = rsqrtf(wave_sum(ss) / (float)width + eps);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const f32x4_t w0 = *(const f32x4_t*)(nw + ch * 8), w1 = *(const f32x4_t*)(nw + ch * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[i][j] = v[i][j] * r * w0[j]; v[i][4 + j] = v[i][4 + j] * r * w1[j]; }
+            }
+        }
+    } else if (NORM == FW_NORM_LN_HEAD) {
+        // head_dim == 64: 8 consecutive chunks = 8 consecutive lanes
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int ch = lane + 64 * i;
+            float s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1 += v[i][j];
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+            const float mean = s1 * (1.0f / 64.0f);
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+            const float r = rsqrtf(s2 * (1.0f / 64.0f) + eps);
+            const int d0 = (ch * 8) & 63;
+            const f32x4_t w0 = *(const f32x4_t*)(nw + d0), w1 = *(const f32x4_t*)(nw + d0 + 4);
+            const f32x4_t b0 = *(const f32x4_t*)(nb + d0), b1 = *(const f32x4_t*)(nb + d0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[i][j] = (v[i][j] - mean) * r * w0[j] + b0[j];
+                v[i][4 + j] = (v[i][4 + j] - mean) * r * w1[j] + b1[j];
+            }
+        }
+    }
+    const float* trow = (ROPE != FW_ROPE_NONE) ? tab + (int64_t)(row % tab_rows) * hd : nullptr;   // [hd/2][2]
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int ch = lane + 64 * i;
+        float o[8];
+        if (ROPE == FW_ROPE_INTERLEAVED) {
+            const int e0 = (ch * 8) % hd;
+            f32x4_t t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
+            if (ch < nch) { t0 = *(const f32x4_t*)(trow + e0); t1 = *(const f32x4_t*)(trow + e0 + 4); }
+            o[0] = v[i][0] * t0[0] - v[i][1] * t0[1]; o[1] = v[i][0] * t0[1] + v[i][1] * t0[0];
+            o[2] = v[i][2] * t0[2] - v[i][3] * t0[3]; o[3] = v[i][2] * t0[3] + v[i][3] * t0[2];
+            o[4] = v[i][4] * t1[0] - v[i][5] * t1[1]; o[5] = v[i][4] * t1[1] + v[i][5] * t1[0];
+            o[6] = v[i][6] * t1[2] - v[i][7] * t1[3]; o[7] = v[i][6] * t1[3] + v[i][7] * t1[2];
+        } else if (ROPE == FW_ROPE_HALF2D) {
+            // hd == 64: chunk k = ch & 7 of the head; y half = chunks 0..3, x half = 4..7; inside a half the first two
+            // chunks are the "lo" 16 elements, partner chunk = k ^ 2 (lane ^ 2); table pair index = hsel*16 + (k&1)*8 + j
+            const int k = ch & 7;
+            const bool lo = (k & 2) == 0;
+            const int pidx = (k >> 2) * 16 + (k & 1) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float partner = __shfl_xor(v[i][j], 2, 64);
+                float cs = 1.f, sn = 0.f;
+                if (ch < nch) { cs = trow[(pidx + j) * 2]; sn = trow[(pidx + j) * 2 + 1]; }
+                o[j] = lo ? (v[i][j] * cs - partner * sn) : (v[i][j] * cs + partner * sn);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[i][j];
+        }
+        if (ch < nch) {
+            u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+            *(u32x4_t*)(xr + ch * 8) = o4;
+        }
+    }
+}
+
+template <int CPL>
+static bool launch_qk_wave(hipStream_t st, uint16_t* x, int64_t ldx, int rows, int heads, int hd, int norm, const float* nw,
+                           const float* nb, float eps, int rope, const float* tab, int tab_rows) {
+    const dim3 grid((rows + 3) / 4), block(256);
+#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows); return true; }
+    FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_INTERLEAVED)
+    FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_NONE)
+    FW_QK_CASE(FW_NORM_NONE, FW_ROPE_INTERLEAVED)
+    FW_QK_CASE(FW_NORM_LN_HEAD, FW_ROPE_HALF2D)
+#undef FW_QK_CASE
+    return false;
+}
+
 __global__ void sinusoid_kernel(const void* __restrict__ t, int t_dtype, float* __restrict__ out, int dim) {
     const int half = dim >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,9 +492,18 @@ extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_
     if (rows <= 0) return 0;
     if (C <= 0 || (C % 4) || C > LN_MAXV * 256 * 4 || (ldx % 4) || (ldy % 4)) { fw_set_error("fw_layernorm_mod: C % 4 == 0, C <= 8192, ld % 4 == 0 required"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
+    if (x_dtype != FW_DT_F32 && x_dtype != FW_DT_BF16) { fw_set_error("fw_layernorm_mod: bad x_dtype"); return FW_E_BADARG; }
+    {   // wave-per-row fast path: needs 16-B aligned rows and parameter vectors
+        const bool xal = x_dtype == FW_DT_F32 ? ((((uintptr_t)x) & 15) == 0) : ((((uintptr_t)x) & 7) == 0);
+        const bool pal = ((((uintptr_t)w) | ((uintptr_t)b) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0;
+        if ((C % 256) == 0 && xal && pal && ((((uintptr_t)y) & 7) == 0)) {
+            const bool ok = x_dtype == FW_DT_F32 ? launch_ln_wave<true>(st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps)
+                                                 : launch_ln_wave<false>(st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps);
+            if (ok) return (int)hipGetLastError();
+        }
+    }
     if (x_dtype == FW_DT_F32) hipLaunchKernelGGL(layernorm_mod_kernel<true>, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, C, w, b, scale, shift, eps);
     else if (x_dtype == FW_DT_BF16) hipLaunchKernelGGL(layernorm_mod_kernel<false>, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, C, w, b, scale, shift, eps);
-    else { fw_set_error("fw_layernorm_mod: bad x_dtype"); return FW_E_BADARG; }
     return (int)hipGetLastError();
 }
 
@@ -322,6 +516,20 @@ extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int hea
     if (norm_mode == FW_NORM_RMS_FULL && !norm_w) { fw_set_error("fw_qk_prep: RMS_FULL needs a weight"); return FW_E_BADARG; }
     if (rope_mode != FW_ROPE_NONE && (!rope_tab || tab_rows <= 0)) { fw_set_error("fw_qk_prep: rope table missing"); return FW_E_BADARG; }
     if (rope_mode == FW_ROPE_HALF2D && (head_dim % 32)) { fw_set_error("fw_qk_prep: HALF2D needs head_dim % 32 == 0"); return FW_E_BADARG; }
+    {   // wave-per-row fast path (table rows and norm vectors 16-B aligned; rotate-half form only for head_dim 64)
+        const bool pal = ((((uintptr_t)norm_w) | ((uintptr_t)norm_b) | ((uintptr_t)rope_tab)) & 15) == 0;
+        const bool shape_ok = (head_dim % 8) == 0 && (rope_mode != FW_ROPE_HALF2D || head_dim == 64) &&
+                              (rope_mode != FW_ROPE_INTERLEAVED || (head_dim % 8) == 0);
+        if (pal && shape_ok) {
+            const int cpl = (width / 8 + 63) / 64;
+            hipStream_t st = (hipStream_t)stream;
+            bool ok = false;
+            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
+            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
+            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
+            if (ok) return (int)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(qk_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, heads, head_dim, norm_mode,
                        norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
     return (int)hipGetLastError();

@@ -59,3 +59,4 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // host-side error plumbing (api.cpp)
 void fw_set_error(const char* msg);
+int fw_get_option(int opt);

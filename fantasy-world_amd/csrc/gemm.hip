@@ -10,6 +10,7 @@
 // deep so concurrently resident tiles share A bands and W panels in L2.
 #include "fw_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -143,6 +144,67 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                     else if (p.res_dtype == FW_DT_BF16) v += bf16_bits_to_f32(((const uint16_t*)p.res)[(int64_t)row * p.ldr + col]);
                     if (p.out_dtype == FW_DT_F32) ((float*)p.C)[(int64_t)row * p.ldc + col] = v;
                     else ((uint16_t*)p.C)[(int64_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+                }
+            }
+        }
+    }
+}
+
+
+// ---- fused epilogue of the 256x256 kernels, through LDS: each wave transposes its 128x64 result in two 64-row passes
+// through a private 16 KiB region (fp32, row stride 256 B), so that global traffic is row-contiguous 16-B (fp32) / 8-B
+// (bf16) per lane: residual loads and output stores touch whole 128-B lines instead of 2-4 B per lane at a row stride.
+// bias / activation / per-column affine are applied on the way in (column == lane in the accumulator layout).
+__device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x16_t (&acc)[4][2], int wave, int grp, int wn,
+                                             int fi, int hi, int lane, int m0, int n0) {
+    {
+        char* reg = smem + wave * 16384;
+        float bias2[2], g12[2], g02[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + wn * 64 + nb * 32 + fi;
+            const bool ok = col < p.N;
+            bias2[nb] = (p.bias && ok) ? p.bias[col] : 0.f;
+            g12[nb] = (p.g1 && ok) ? p.g1[col] : 1.f;
+            g02[nb] = (p.g0 && ok) ? p.g0[col] : 0.f;
+        }
+        const int rl = lane >> 4;              // row inside a 4-row read group
+        const int c4 = (lane & 15) * 4;        // first of this lane's 4 columns
+        const int gcol = n0 + wn * 64 + c4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[2 * q + rb2][nb][r] + bias2[nb];
+                        v = fw_apply_act(v, p.act);
+                        v = v * g12[nb] + g02[nb];
+                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
+                    }
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row_l = it * 4 + rl;
+                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
+                const int row = m0 + grp * 128 + q * 64 + row_l;
+                if (row < p.M && gcol < p.N) {
+                    if (p.res_dtype == FW_DT_F32) {
+                        const f32x4_t rv = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+                        v += rv;
+                    } else if (p.res_dtype == FW_DT_BF16) {
+                        const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
+                        v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
+                    }
+                    if (p.out_dtype == FW_DT_F32) {
+                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                    } else {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                    }
                 }
             }
         }
@@ -310,62 +372,525 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs p) {
     }
     if (grp == 0) FW_BARRIER();
 
-    // ---- epilogue through LDS: each wave transposes its 128x64 result in two 64-row passes through a private 16 KiB
-    // region (fp32, row stride 256 B), so that global traffic is row-contiguous 16-B (fp32) / 8-B (bf16) per lane:
-    // residual loads and output stores touch whole 128-B lines instead of 2-4 B per lane at a row stride.
-    // bias / activation / per-column affine are applied on the way in (column == lane in the accumulator layout).
+    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256 tile, k streamed in HALF-SLABS of 32 through a 5-deep LDS ring (5 x 32 KiB = all 160 KiB of the CU).
+//
+// Why: with two 64 KiB stages a slab's DMA has at most ~1 slab time to land and every slab ends in vmcnt(0); a
+// global_load_lds that misses L2 needs ~1-2.5k cycles under load, so the matrix pipe idles on the slowest piece of every
+// slab.  Here a half-slab is requested FOUR half-slabs (8 barrier slots) before its first read and retired with a COUNTED
+// vmcnt (12 / 8 pieces still in flight), so the loop never drains the DMA queue.
+//
+// 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 8 accumulators of 32x32 (v_mfma_f32_32x32x16_bf16); per half-slab a wave
+// does 12 ds_read_b128 (A 4x2, B 2x2) and 16 MFMA.  The two 4-wave groups (waves sharing a SIMD are in different groups)
+// run one barrier slot apart, so one is in its MFMA burst while its SIMD partner reads LDS:
+//     slot:        2h          2h+1        2h+2
+//     group A:   LOAD(h)     MFMA(h)     LOAD(h+1)
+//     group B:   MFMA(h-1)   LOAD(h)     MFMA(h)
+// Ring slot h%5 is last read in slot 2h+1 (reads drained with lgkmcnt(0) before the barrier), and rewritten with half-slab
+// h+5-1 = h+4's successor: every wave issues its 4 pieces of half-slab h+4 from INSIDE MFMA(h) (slot >= 2h+1 > 2(h-1)+1),
+// interleaved with the MFMAs so the issue cost hides behind the matrix pipe.  Half-slab j must be complete before group A's
+// LOAD(j) in slot 2j: group A waits vmcnt(12) at the end of MFMA(j-1) (younger: j+1..j+3), group B waits vmcnt(8) at the end
+// of LOAD(j-1) (younger: j+1, j+2); both waits precede the barrier that ends slot 2j-1.
+// LDS image of a half-slab: 512 rows (256 A, 256 W) x 64 B, 16-B chunk index XOR ((row>>2)&3) -- applied to the per-lane
+// SOURCE address of the DMA (destination is lane-linear) and again on the read: conflict-free ds_read_b128.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HK = 32;                          // k per half-slab
+constexpr int RING = 5;
+constexpr int HSLAB = (TM + TN) * HK * 2;       // 32 KiB
+
+template <int N> __device__ __forceinline__ void fw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(GemmArgs p) {
+    constexpr bool PRIO = (VAR & 1) != 0;        // s_setprio(1) around the MFMA burst
+    constexpr bool DMA_HEAD = (VAR & 2) != 0;    // issue the 4 DMA pieces in front of the burst instead of inside it
+    constexpr bool NO_DMA = (VAR & 4) != 0;      // ablation: never restage (wrong results; measures the LDS/MFMA/barrier loop)
+    constexpr bool DMA_LOAD = (VAR & 8) != 0;    // issue the 4 DMA pieces from the LOAD slot (while the SIMD partner owns the matrix pipe)
+    constexpr bool ROW128 = (VAR & 64) != 0;     // ablation (wrong results): every DMA instruction reads 8 rows x 128 B instead of 16 rows x 64 B
+    constexpr bool FEW_LANES = (VAR & 32) != 0;  // ablation (wrong results): only 4 lanes of every DMA instruction active (same instruction count, 1/16 of the bytes)
+    constexpr bool SAME_ADDR = (VAR & 16) != 0;  // ablation (wrong results): every DMA re-reads half-slab 0 (L2-hot) -- memory system vs CU-internal cost
+    __shared__ __attribute__((aligned(16))) char smem[RING * HSLAB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
     {
-        char* reg = smem + wave * 16384;
-        float bias2[2], g12[2], g02[2];
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // ---- DMA addressing: wave w streams A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of every half-slab (1 KiB = 16 rows x 64 B).
+    // Uniform 64-bit base (SGPR pair, advanced by 64 B per half-slab) + per-lane unsigned 32-bit byte offset (VGPR): the
+    // saddr form of global_load_lds, no per-piece 64-bit VALU address arithmetic.
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[2], woff[2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int col = n0 + wn * 64 + nb * 32 + fi;
-            const bool ok = col < p.N;
-            bias2[nb] = (p.bias && ok) ? p.bias[col] : 0.f;
-            g12[nb] = (p.g1 && ok) ? p.g1[col] : 1.f;
-            g02[nb] = (p.g0 && ok) ? p.g0[col] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        int row = (wave * 2 + i) * 16 + (lane >> 2);
+        int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        if (ROW128) { row = (wave * 2 + i) * 16 + (lane >> 3); chunk = lane & 7; }
+        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+    }
+#define FW_RING_PIECE_A(RS, H, I) if (!FEW_LANES || lane < 4) FW_GLDS16(abase + (size_t)(SAME_ADDR ? 0 : (H)) * (HK * 2) + aoff[I], smem + (RS) * HSLAB + (wave * 2 + (I)) * 1024)
+#define FW_RING_PIECE_W(RS, H, I) if (!FEW_LANES || lane < 4) FW_GLDS16(wbase + (size_t)(SAME_ADDR ? 0 : (H)) * (HK * 2) + woff[I], smem + (RS) * HSLAB + TM * HK * 2 + (wave * 2 + (I)) * 1024)
+
+    // ---- fragment read offsets: row R, logical chunk c = 2*ks + hi, physical chunk = c ^ ((R>>2)&3) ---------------------
+    const int fi = lane & 31, hi = lane >> 5;
+    const int f = (fi >> 2) & 3;
+    const int a_off0 = (grp * 128 + fi) * 64 + (((0 + hi) ^ f) << 4);
+    const int a_off1 = (grp * 128 + fi) * 64 + (((2 + hi) ^ f) << 4);
+    const int b_off0 = TM * HK * 2 + (wn * 64 + fi) * 64 + (((0 + hi) ^ f) << 4);
+    const int b_off1 = TM * HK * 2 + (wn * 64 + fi) * 64 + (((2 + hi) ^ f) << 4);
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t afr[4][2], bfr[2][2];
+
+    const int nh = p.K / HK;        // >= 8 (launcher)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        FW_RING_PIECE_A(h, h, 0); FW_RING_PIECE_W(h, h, 0); FW_RING_PIECE_A(h, h, 1); FW_RING_PIECE_W(h, h, 1);
+    }
+    fw_wait_vm<12>();
+    FW_BARRIER();
+    if (grp == 1) FW_BARRIER();
+
+    int rs = 0;                      // ring slot of half-slab h
+    int h = 0;
+    // one LOAD(h) | barrier | MFMA(h) (+ DMA of half-slab h+4 when MORE) | barrier
+    auto iter = [&](auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value && !NO_DMA;
+        // ------------------------------------------------ LOAD(h)
+        {
+            const char* base = smem + rs * HSLAB;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                bfr[nb][0] = *(const bf16x8_t*)(base + b_off0 + nb * 2048);
+                bfr[nb][1] = *(const bf16x8_t*)(base + b_off1 + nb * 2048);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                afr[rb][0] = *(const bf16x8_t*)(base + a_off0 + rb * 2048);
+                afr[rb][1] = *(const bf16x8_t*)(base + a_off1 + rb * 2048);
+            }
         }
-        const int rl = lane >> 4;              // row inside a 4-row read group
-        const int c4 = (lane & 15) * 4;        // first of this lane's 4 columns
-        const int gcol = n0 + wn * 64 + c4;
+        const int ns = rs == 0 ? 4 : rs - 1;
+        if (DMA_LOAD && MORE) {
+            // ring slot ns held half-slab h-1, last read in slot 2h-1 (group B's LOAD(h-1)); this LOAD runs in slot >= 2h
+            FW_RING_PIECE_A(ns, h + 4, 0); FW_RING_PIECE_W(ns, h + 4, 0); FW_RING_PIECE_A(ns, h + 4, 1); FW_RING_PIECE_W(ns, h + 4, 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) {
+            if (!decltype(more_tag)::value) fw_wait_vm<0>();
+            else if (DMA_LOAD) fw_wait_vm<12>();      // younger than half-slab h+1: h+2, h+3, h+4
+            else fw_wait_vm<8>();                     // younger than half-slab h+1: h+2, h+3
+        }
+        FW_BARRIER();
+        // ------------------------------------------------ MFMA(h), DMA of half-slab h+4 into ring slot (rs+4)%5
+        if (DMA_HEAD && !DMA_LOAD && MORE) {
+            FW_RING_PIECE_A(ns, h + 4, 0); FW_RING_PIECE_W(ns, h + 4, 0); FW_RING_PIECE_A(ns, h + 4, 1); FW_RING_PIECE_W(ns, h + 4, 1);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int rb2 = 0; rb2 < 2; ++rb2)
+            for (int rb = 0; rb < 4; ++rb) {
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[rb][ks], bfr[0][ks], acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[rb][ks], bfr[1][ks], acc[rb][1], 0, 0, 0);
+                if (!DMA_HEAD && !DMA_LOAD && MORE) {
+                    // one DMA piece after MFMAs 2, 6, 10, 14 of the burst
+                    if (ks == 0 && rb == 0) FW_RING_PIECE_A(ns, h + 4, 0);
+                    if (ks == 0 && rb == 2) FW_RING_PIECE_W(ns, h + 4, 0);
+                    if (ks == 1 && rb == 0) FW_RING_PIECE_A(ns, h + 4, 1);
+                    if (ks == 1 && rb == 2) FW_RING_PIECE_W(ns, h + 4, 1);
+                }
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) { if (decltype(more_tag)::value) fw_wait_vm<12>(); else fw_wait_vm<0>(); }
+        FW_BARRIER();
+        rs = rs == RING - 1 ? 0 : rs + 1;
+    };
+    for (; h < nh - 4; ++h) iter(std::true_type{});
+    for (; h < nh; ++h) iter(std::false_type{});
+    if (grp == 0) FW_BARRIER();
+    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256 tile with FOUR waves (256 threads), one wave per SIMD owning the whole register file: wave tile 128 x 128 =
+// 16 accumulators of 32x32 (256 accumulator registers, placed in the AGPR half by the compiler) + fragments / addresses
+// in the 256 architectural VGPRs.  No inter-wave ping-pong: every wave software-pipelines ITS OWN stream -- fragment
+// ds_reads of the next k-step and the LDS-DMA of a later half-slab are issued between the MFMAs of the current k-step
+// (32 MFMAs per 32-wide half-slab, one ds_read_b128 per 2 MFMAs, one DMA piece per 4), so the matrix pipe is fed by a
+// single in-order instruction stream and there is only ONE barrier per half-slab (DMA visibility + ring reuse).
+// LDS traffic per slab drops to 2/3 of the 8-wave kernels (wave tile 128x128 instead of 128x64).
+// Ring: the same 5 x 32 KiB half-slab ring and swizzle as gemm_bf16_ring_kernel.  In iteration h (compute half-slab h) the
+// wave issues its 8 pieces of half-slab h+4 into the slot of half-slab h-1 (all reads of h-1 retired before the barrier
+// of iteration h-1) and, before the barrier that opens half-slab h+1, waits vmcnt(20): younger than its pieces of h+1 are
+// h+2, h+3 (16) and the first 4 pieces of h+4.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x16_t (&acc)[4][4], int wave, int wm, int wn,
+                                            int fi, int hi, int lane, int m0, int n0) {
+    // Pass rb: the wave's 32 x 128 fp32 block goes through a private 16 KiB LDS region (raw accumulators in, row-contiguous
+    // 16 B per lane out); bias / activation / per-column affine / residual are applied on the way out, where a lane owns 4
+    // fixed columns and whole 512-B (fp32) / 256-B (bf16) row segments are read and written.
+    char* reg = smem + wave * 16384;
+    const int rl = lane >> 5;                  // row inside a 2-row read group
+    const int c4 = (lane & 31) * 4;            // first of this lane's 4 columns
+    const int gcol = n0 + wn * 128 + c4;
+    const bool col_ok = gcol < p.N;            // N % 4 == 0 (launcher): the 4 columns are valid together
+    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f}, g14 = {1.f, 1.f, 1.f, 1.f}, g04 = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok) {
+        if (p.bias) bias4 = *(const f32x4_t*)(p.bias + gcol);
+        if (p.g1) g14 = *(const f32x4_t*)(p.g1 + gcol);
+        if (p.g0) g04 = *(const f32x4_t*)(p.g0 + gcol);
+    }
+    const int act = p.act;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+    for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[2 * q + rb2][nb][r] + bias2[nb];
-                        v = fw_apply_act(v, p.act);
-                        v = v * g12[nb] + g02[nb];
-                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
-                    }
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int row_l = it * 4 + rl;
-                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
-                const int row = m0 + grp * 128 + q * 64 + row_l;
-                if (row < p.M && gcol < p.N) {
-                    if (p.res_dtype == FW_DT_F32) {
-                        const f32x4_t rv = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
-                        v += rv;
-                    } else if (p.res_dtype == FW_DT_BF16) {
-                        const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
-                        v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
-                        v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
-                    }
-                    if (p.out_dtype == FW_DT_F32) {
-                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
-                    } else {
-                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
-                    }
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row_l = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                *(float*)(reg + row_l * 512 + (nb * 32 + fi) * 4) = acc[rb][nb][r];
+            }
+#pragma unroll 2
+        for (int it = 0; it < 16; ++it) {
+            const int row_l = it * 2 + rl;
+            f32x4_t v = *(const f32x4_t*)(reg + row_l * 512 + c4 * 4);
+            const int row = m0 + wm * 128 + rb * 32 + row_l;
+            if (row < p.M && col_ok) {
+                v += bias4;
+                if (act != FW_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
+                }
+                v = v * g14 + g04;
+                if (p.res_dtype == FW_DT_F32) {
+                    const f32x4_t rv = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+                    v += rv;
+                } else if (p.res_dtype == FW_DT_BF16) {
+                    const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
+                    v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
+                }
+                if (p.out_dtype == FW_DT_F32) {
+                    *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                } else {
+                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
                 }
             }
         }
     }
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
+    constexpr bool PRIO = (VAR & 1) != 0;
+    constexpr bool NO_DMA = (VAR & 4) != 0;      // ablation (wrong results)
+    __shared__ __attribute__((aligned(16))) char smem[RING * HSLAB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // DMA: wave w streams A pieces 4w..4w+3 and W pieces 4w..4w+3 of every half-slab (1 KiB = 16 rows x 64 B)
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+    }
+#define FW_W4_PIECE_A(RS, H, I) FW_GLDS16(abase + (size_t)(H) * (HK * 2) + aoff[I], smem + (RS) * HSLAB + (wave * 4 + (I)) * 1024)
+#define FW_W4_PIECE_W(RS, H, I) FW_GLDS16(wbase + (size_t)(H) * (HK * 2) + woff[I], smem + (RS) * HSLAB + TM * HK * 2 + (wave * 4 + (I)) * 1024)
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int f = (fi >> 2) & 3;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_off[ks] = (wm * 128 + fi) * 64 + (((2 * ks + hi) ^ f) << 4);
+        b_off[ks] = TM * HK * 2 + (wn * 128 + fi) * 64 + (((2 * ks + hi) ^ f) << 4);
+    }
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t a0[4], b0[4], a1[4], b1[4];         // fragment sets of k-step 0 / 1 of a half-slab
+
+    const int nh = p.K / HK;        // >= 8 (launcher)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { FW_W4_PIECE_A(h, h, i); FW_W4_PIECE_W(h, h, i); }
+    }
+    fw_wait_vm<24>();
+    FW_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a0[i] = *(const bf16x8_t*)(smem + a_off[0] + i * 2048);
+        b0[i] = *(const bf16x8_t*)(smem + b_off[0] + i * 2048);
+    }
+
+    int rs = 0;
+    int h = 0;
+    auto iter = [&](auto more_tag, auto last_tag) {
+        constexpr bool MORE = decltype(more_tag)::value && !NO_DMA;     // half-slab h+4 exists
+        constexpr bool LAST = decltype(last_tag)::value;                // h == nh-1
+        const char* base = smem + rs * HSLAB;
+        const int ns = rs == 0 ? 4 : rs - 1;       // ring slot of half-slab h+4 (== h-1)
+        const int nx = rs == RING - 1 ? 0 : rs + 1;
+        // ---- k-step 0: prefetch k-step 1 fragments, first half of the DMA, 16 MFMAs on set 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a1[i] = *(const bf16x8_t*)(base + a_off[1] + i * 2048);
+            b1[i] = *(const bf16x8_t*)(base + b_off[1] + i * 2048);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[rb], b0[nb], acc[rb][nb], 0, 0, 0);
+            if (MORE) { if (rb & 1) FW_W4_PIECE_W(ns, h + 4, rb >> 1); else FW_W4_PIECE_A(ns, h + 4, rb >> 1); }
+        }
+        // ---- k-step 1: open half-slab h+1 (own pieces landed -> barrier), prefetch its k-step 0, rest of the DMA, 16 MFMAs
+        if (!LAST) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (MORE) fw_wait_vm<20>(); else fw_wait_vm<0>();
+            FW_BARRIER();
+            const char* nbase = smem + nx * HSLAB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0[i] = *(const bf16x8_t*)(nbase + a_off[0] + i * 2048);
+                b0[i] = *(const bf16x8_t*)(nbase + b_off[0] + i * 2048);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rb], b1[nb], acc[rb][nb], 0, 0, 0);
+            if (MORE) { if (rb & 1) FW_W4_PIECE_W(ns, h + 4, 2 + (rb >> 1)); else FW_W4_PIECE_A(ns, h + 4, 2 + (rb >> 1)); }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        rs = nx;
+    };
+    for (; h < nh - 4; ++h) iter(std::true_type{}, std::false_type{});
+    for (; h < nh - 1; ++h) iter(std::false_type{}, std::false_type{});
+    iter(std::false_type{}, std::true_type{});
+    FW_BARRIER();
+    epilogue_w4(p, smem, acc, wave, wm, wn, fi, hi, lane, m0, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256x64 ping-pong kernel, 128-B LDS rows, two 64 KiB stages, quarter-slab DMA scheduling with counted waits.
+//
+// Measured on MI355X (tools/probes/dma_probe.hip): the LDS-DMA ingest of a CU tops out at ~107 GB/s with 128-B global
+// rows but only ~67 GB/s with 64-B rows (57 vs 85 GB/s beside ds_read traffic), and the GEMM's cost scales with the BYTES
+// it streams, not with the number of DMA instructions.  So this kernel keeps full 128-B rows (k-slab 64) like
+// gemm_bf16_256_kernel, and gets its prefetch distance from scheduling instead of from more LDS: a slab is four 16 KiB
+// units -- A0 = tile rows 0..127 (read only by wave group A), A1 = rows 128..255 (group B), B0/B1 = the W rows -- and a
+// unit of slab t+2 is requested as soon as the same unit of slab t has been read for the last time:
+//     slot:        4t        4t+1      4t+2      4t+3      4t+4
+//     group A:   LOAD0(t)  MFMA0(t)  LOAD1(t)  MFMA1(t)  LOAD0(t+1)      LOAD0 reads B(t) + A rows 0-63 of the wave tile,
+//     group B:   MFMA1(..) LOAD0(t)  MFMA0(t)  LOAD1(t)  MFMA1(t)        LOAD1 reads A rows 64-127
+//   B(t) is last read in slot 4t+1, A0(t) in 4t+2, A1(t) in 4t+3.  Every wave issues, from inside its MFMA1(t) burst (slot
+//   4t+3 / 4t+4), its 6 pieces of B(t+2) and A0(t+2), and from MFMA0(t+1) its 2 pieces of A1(t+2): 4-5 slots (~one slab
+//   time) before the first read in slot 4t+8 / 4t+9.  Waits are counted (never vmcnt(0) in steady state):
+//     group A: end of MFMA1(t): vmcnt(8) -> own B/A0(t+1) landed;   end of LOAD0(t): vmcnt(6) -> own A1(t) landed
+//     group B: end of LOAD1(t): vmcnt(2) -> own B/A0(t+1) landed;   end of MFMA1(t): vmcnt(6) -> own A1(t+1) landed
+//   each ahead of the barrier that precedes the first read of that unit by any wave.
+// ---------------------------------------------------------------------------------------------------------------
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
+    constexpr bool PRIO = (VAR & 1) != 0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // DMA pieces (1 KiB = 8 rows x 128 B).  Wave w owns, in every 128-row unit, pieces 2w and 2w+1 (rows 16w .. 16w+15).
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[2][2], woff[2][2];       // [unit][piece]
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = u * 128 + (wave * 2 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            aoff[u][i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+            woff[u][i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+        }
+#define FW_PP_A(S, KT, U, I) FW_GLDS16(abase + (size_t)(KT) * (BK * 2) + aoff[U][I], smem + (S) * STAGE2 + ((U) * 16 + wave * 2 + (I)) * 1024)
+#define FW_PP_W(S, KT, U, I) FW_GLDS16(wbase + (size_t)(KT) * (BK * 2) + woff[U][I], smem + (S) * STAGE2 + TM * BK * 2 + ((U) * 16 + wave * 2 + (I)) * 1024)
+#define FW_PP_ISSUE6(S, KT) do { FW_PP_W(S, KT, 0, 0); FW_PP_W(S, KT, 0, 1); FW_PP_W(S, KT, 1, 0); FW_PP_W(S, KT, 1, 1); FW_PP_A(S, KT, 0, 0); FW_PP_A(S, KT, 0, 1); } while (0)
+#define FW_PP_ISSUE2(S, KT) do { FW_PP_A(S, KT, 1, 0); FW_PP_A(S, KT, 1, 1); } while (0)
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + hi) ^ swz) << 4;
+    const int a_row_off = (grp * 128 + fi) * 128;                    // + rb*32*128, rb = 0..3
+    const int b_row_off = TM * BK * 2 + (wn * 64 + fi) * 128;        // + nb*32*128
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t afr[2][4], bfr[2][4];
+
+    const int nk = p.K / BK;       // >= 4 (launcher)
+    FW_PP_ISSUE6(0, 0); FW_PP_ISSUE2(0, 0);
+    FW_PP_ISSUE6(1, 1); FW_PP_ISSUE2(1, 1);
+    fw_wait_vm<8>();
+    FW_BARRIER();
+    if (grp == 1) FW_BARRIER();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = smem + (kt & 1) * STAGE2;
+        const int st = kt & 1;
+        const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+        // ---------------- LOAD0(kt): B fragments + A rows 0..63 of the wave tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bfr[0][ks] = *(const bf16x8_t*)(base + b_row_off + coff[ks]);
+            bfr[1][ks] = *(const bf16x8_t*)(base + b_row_off + 32 * 128 + coff[ks]);
+            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + coff[ks]);
+            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 32 * 128 + coff[ks]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 0) { if (has1) fw_wait_vm<6>(); else fw_wait_vm<0>(); }
+        FW_BARRIER();
+        // ---------------- MFMA0(kt) (+ A1 unit of slab kt+1 into the other stage; slabs 0 and 1 come from the prologue)
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[0][1], 0, 0, 0);
+            if (ks == 0 && kt >= 1 && has1) FW_PP_ISSUE2(st ^ 1, kt + 1);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[1][1], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        FW_BARRIER();
+        // ---------------- LOAD1(kt): A rows 64..127 of the wave tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + 64 * 128 + coff[ks]);
+            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 96 * 128 + coff[ks]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) { if (has1) fw_wait_vm<2>(); else fw_wait_vm<0>(); }
+        FW_BARRIER();
+        // ---------------- MFMA1(kt) (+ B and A0 units of slab kt+2 into this stage)
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[2][1], 0, 0, 0);
+            if (ks == 0 && has2) FW_PP_ISSUE6(st, kt + 2);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[3][1], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) { if (has2) fw_wait_vm<8>(); else if (has1) fw_wait_vm<2>(); else fw_wait_vm<0>(); }
+        else { if (has2) fw_wait_vm<6>(); else fw_wait_vm<0>(); }
+        FW_BARRIER();
+    }
+    if (grp == 0) FW_BARRIER();
+    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
 }
 
 // fp32 GEMV for the M=1 time-embedding MLPs: one wave per output feature.
@@ -407,7 +932,7 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     p.res = res; p.ldr = ldr; p.res_dtype = res ? res_dtype : FW_DT_NONE;
     // tile choice: the 256x256 staggered kernel for the big token-major GEMMs, 128x128 otherwise.
     // FW_GEMM_TILE=128|256 forces one (A/B measurements).
-    static const int forced = [] { const char* e = getenv("FW_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    const int forced = fw_get_option(FW_OPT_GEMM_TILE);
     bool big = (M >= 2048 && N >= 1024);
     if (forced == 128) big = false;
     if (forced == 256) big = true;
@@ -415,12 +940,44 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     const uintptr_t cmask = (out_dtype == FW_DT_F32) ? 15 : 7;
     const uintptr_t rmask = (res_dtype == FW_DT_F32) ? 15 : 7;
     if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & cmask) || (res && ((ldr % 4) || (((uintptr_t)res) & rmask)))) big = false;
+    if ((((uintptr_t)bias) | ((uintptr_t)g1) | ((uintptr_t)g0)) & 15) big = false;   // per-column vectors are read 16 B at a time
     if (big) {
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
-        static const int var = [] { const char* e = getenv("FW_GEMM_VAR"); return e ? atoi(e) : 0; }();
+        const int var = fw_get_option(FW_OPT_GEMM_VAR);
+        const int kern = fw_get_option(FW_OPT_GEMM_KERNEL);   // 1 = ring (default), 0 = 2-stage staggered
         hipStream_t st = (hipStream_t)stream;
+        if (kern == 3 && K >= 4 * BK) {
+            if (var == 1) hipLaunchKernelGGL(gemm_bf16_pp_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+            else hipLaunchKernelGGL(gemm_bf16_pp_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+            return (int)hipGetLastError();
+        }
+        if (kern == 2 && K >= 8 * HK) {
+            switch (var) {
+                case 1: hipLaunchKernelGGL(gemm_bf16_w4_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, p); break;
+                case 4: hipLaunchKernelGGL(gemm_bf16_w4_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, p); break;
+                default: hipLaunchKernelGGL(gemm_bf16_w4_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, p); break;
+            }
+            return (int)hipGetLastError();
+        }
+        if (kern == 1 && K >= 8 * HK) {
+            switch (var) {
+                case 1: hipLaunchKernelGGL(gemm_bf16_ring_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 2: hipLaunchKernelGGL(gemm_bf16_ring_kernel<2>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 3: hipLaunchKernelGGL(gemm_bf16_ring_kernel<3>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 4: hipLaunchKernelGGL(gemm_bf16_ring_kernel<4>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 5: hipLaunchKernelGGL(gemm_bf16_ring_kernel<5>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 8: hipLaunchKernelGGL(gemm_bf16_ring_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 9: hipLaunchKernelGGL(gemm_bf16_ring_kernel<9>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 16: hipLaunchKernelGGL(gemm_bf16_ring_kernel<16>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 32: hipLaunchKernelGGL(gemm_bf16_ring_kernel<32>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 48: hipLaunchKernelGGL(gemm_bf16_ring_kernel<48>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                case 64: hipLaunchKernelGGL(gemm_bf16_ring_kernel<64>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+                default: hipLaunchKernelGGL(gemm_bf16_ring_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+            }
+            return (int)hipGetLastError();
+        }
         switch (var) {
             case 1: hipLaunchKernelGGL(gemm_bf16_256_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
             case 2: hipLaunchKernelGGL(gemm_bf16_256_kernel<2>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;

@@ -22,7 +22,7 @@ ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
 SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
-    "fw_cast_f32_bf16",
+    "fw_cast_f32_bf16", "fw_set_option",
 ]
 
 _lib = None
@@ -56,6 +56,7 @@ def load_library(path: str = LIB_PATH):
         "fw_unpatchify": [vp, i64, vp, i32, i32, i32, i32, vp],
         "fw_assemble_tokens": [vp, i64, vp, vp, i32, i32, i32, i32, vp],
         "fw_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
+        "fw_set_option": [i32, i32],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -131,6 +132,12 @@ class HipOps:
         return sum(ms) / len(ms), len(ms)
 
     # ---- memory plumbing ------------------------------------------------------------------------------------
+    OPTS = {"gemm_tile": 0, "gemm_kernel": 1, "gemm_var": 2, "attn_var": 3}
+
+    def set_option(self, name, value):
+        """A/B knob (include/fw_mi355x.h FW_OPT_*); never changes results."""
+        _check(self.lib.fw_set_option(self.OPTS[name], int(value)), "fw_set_option")
+
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 

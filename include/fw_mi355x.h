@@ -55,6 +55,18 @@ extern "C" {
 
 int fw_abi_version(void);
 
+/*
+ * Kernel-selection knobs for A/B measurements (tools/microbench.py); results never depend on them.
+ * Each slot is initialised once from the environment variable of the same name.
+ */
+#define FW_OPT_GEMM_TILE   0   /* FW_GEMM_TILE: 0 = auto, 128 / 256 = force the tile family */
+#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 3 = 128-B-row ping-pong with quarter-slab DMA (default), 1 = 5-deep half-slab ring,
+                                  2 = four-wave 128x128 wave tile, 0 = first 2-stage staggered kernel (A/B baselines) */
+#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: schedule variant bits of the selected 256x256 kernel (default 1 = s_setprio around MFMA bursts) */
+#define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: schedule variant bits of the attention kernel */
+#define FW_OPT_COUNT       4
+int fw_set_option(int opt, int value);
+
 /* Human-readable description of the last negative error on this thread (never NULL). */
 const char* fw_last_error(void);
 

@@ -88,6 +88,53 @@ def test_gemm_strided_views(ops, ref):
     assert outbuf[:, :N].abs().max().item() == 0.0
 
 
+# the 256x256 kernels (M >= 2048, N >= 1024): 5-deep half-slab ring (default) and the 2-stage staggered kernel accumulate
+# in the same k order, so they must agree BIT FOR BIT with each other, and with the fp32 reference to rounding.
+RING_SHAPES = [(2048, 1024, 256), (2300, 1280, 320), (4095, 1152, 1024), (2051, 2304, 576), (2560, 1024, 4096)]
+
+
+@pytest.mark.parametrize("M,N,K", RING_SHAPES)
+def test_gemm_ring_kernel_shapes(ops, ref, M, N, K):
+    x, w, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23, scale=0.1)
+    want = ref.linear(x, ref.pack_linear(w, b), out_f32=True)
+    lin = ops.pack_linear(w, b)
+    xd = bf(x).cuda()
+    try:
+        outs = {}
+        for kern in (1, 0, 2, 3):
+            ops.set_option("gemm_kernel", kern)
+            for var in {1: (0, 1, 8), 0: (0,), 2: (0,), 3: (0, 1)}[kern]:
+                ops.set_option("gemm_var", var)
+                outs[(kern, var)] = ops.linear(xd, lin, out_f32=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("gemm_kernel", 3)
+        ops.set_option("gemm_var", 1)
+    assert rel_l2(outs[(3, 1)], want) < 1e-3
+    for key, o in outs.items():
+        assert torch.equal(o, outs[(3, 1)]), key
+
+
+@pytest.mark.parametrize("kern", [1, 2, 3])
+@pytest.mark.parametrize("res_dtype,out_f32", [("f32", True), ("bf16", False)])
+def test_gemm_ring_kernel_fused_epilogue(ops, ref, res_dtype, out_f32, kern):
+    """gelu + per-column affine + residual on the big-tile path, ragged M and N tails, in place on the residual."""
+    M, N, K = 2333, 1028, 512
+    x, w, b = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33, scale=0.1)
+    g1, g0 = rnd(N, seed=34), rnd(N, seed=35)
+    res = rnd(M, N, seed=36) if res_dtype == "bf16" else torch.randn(M, N, generator=torch.Generator().manual_seed(36))
+    want = ref.linear(x, ref.pack_linear(w, b), act="gelu_tanh", g1=g1, g0=g0, res=res, out_f32=True)
+    r = res.cuda().to(torch.bfloat16 if res_dtype == "bf16" else torch.float32)
+    ops.set_option("gemm_kernel", kern)
+    try:
+        got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), act="gelu_tanh", g1=g1.cuda(), g0=g0.cuda(), res=r,
+                         out_f32=out_f32, out=r)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("gemm_kernel", 3)
+    assert rel_l2(got.float(), want) < (1e-3 if out_f32 else 4e-3)
+
+
 def test_gemm_rejects_bad_k(ops):
     x = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
     from fantasy_world_amd.hip_ops import Linear
@@ -179,7 +226,8 @@ def test_attention_rejects_bad_head_dim(ops):
 # --------------------------------------------------------------------------------------------------------- norms / rope
 @pytest.mark.parametrize("C,rows,affine,mod,xdt", [(5120, 70, False, True, "f32"), (5120, 33, True, False, "f32"),
                                                    (1024, 129, True, True, "f32"), (1280, 257, True, False, "bf16"),
-                                                   (5120, 5, True, False, "bf16")])
+                                                   (5120, 5, True, False, "bf16"), (2048, 9, True, False, "f32"),
+                                                   (1000, 7, True, True, "f32"), (8192, 3, False, True, "f32")])
 def test_layernorm_mod(ops, ref, C, rows, affine, mod, xdt):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(rows, C, generator=g) * 3 + 0.5

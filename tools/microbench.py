@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--L", type=int, default=32760)
+    ap.add_argument("--gemm-variants", default="", help="comma list of kernel:var pairs to A/B, e.g. 1:0,1:1,0:0")
+    ap.add_argument("--attn-variants", default="", help="comma list of FW_ATTN_VAR values to A/B")
     args = ap.parse_args()
     ops = HipOps("cuda:0")
     dev = "cuda:0"
@@ -41,7 +43,13 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rb = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
 
+    gvars = [tuple(int(a) for a in v.split(":")) for v in args.gemm_variants.split(",") if v] or [(3, 1)]
+    avars = [int(v) for v in args.attn_variants.split(",") if v] or [0]
     if args.only in ("", "gemm"):
+      for (gk, gv) in gvars:
+        ops.set_option("gemm_kernel", gk)
+        ops.set_option("gemm_var", gv)
+        print(f"== gemm kernel={gk} var={gv}", flush=True)
         for (M, N, K, tag) in [(L, 15360, 5120, "dit qkv"), (L, 5120, 5120, "dit o/q"), (L, 13824, 5120, "ffn0"),
                                (L, 5120, 13824, "ffn2"), (L2, 3072, 1024, "vggt qkv"), (L2, 4096, 1024, "vggt fc1"),
                                (L2, 1024, 4096, "vggt fc2"), (L, 2304, 5120, "bicross qv1"), (L, 5120, 1152, "bicross out1"),
@@ -51,10 +59,24 @@ def main():
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             ms = timeit(lambda: ops.linear(x, lin, out=out), args.iters)
             tf = 2.0 * M * N * K / ms / 1e9
-            res.append(dict(kernel="gemm", tag=tag, M=M, N=N, K=K, ms=ms, tflops=tf, frac=tf / 2500))
+            res.append(dict(kernel="gemm", variant=f"{gk}:{gv}", tag=tag, M=M, N=N, K=K, ms=ms, tflops=tf, frac=tf / 2500))
             print(f"gemm {tag:14s} M={M:6d} N={N:6d} K={K:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s  {tf/25:5.1f}% of peak", flush=True)
+            if tag in ("dit o/q", "vggt fc2"):
+                # the same GEMM as the engine runs it: gate * (acc + bias) + fp32 residual, in place on the fp32 stream
+                xs = torch.randn(M, N, device=dev)
+                gate = torch.randn(N, device=dev)
+                ms = timeit(lambda: ops.linear(x, lin, g1=gate, res=xs, out_f32=True, out=xs), args.iters)
+                tf = 2.0 * M * N * K / ms / 1e9
+                res.append(dict(kernel="gemm+res_f32", variant=f"{gk}:{gv}", tag=tag, M=M, N=N, K=K, ms=ms, tflops=tf))
+                print(f"gemm {tag:14s} + gate + fp32 residual in place      {ms:8.3f} ms  {tf:7.1f} TF/s", flush=True)
+                del xs, gate
             del x, lin, out
+      ops.set_option("gemm_kernel", 3)
+      ops.set_option("gemm_var", 1)
     if args.only in ("", "attn"):
+      for av in avars:
+        ops.set_option("attn_var", av)
+        print(f"== attention var={av}", flush=True)
         for (H, hd, B, Lq, Lk, tag) in [(40, 128, 1, L, L, "dit self"), (40, 128, 1, L, 512, "dit cross txt"),
                                         (12, 96, 1, L, L2, "bicross"), (16, 64, 1, L2, L2, "vggt global"),
                                         (16, 64, 21, L2 // 21, L2 // 21, "vggt frame")]:
@@ -63,12 +85,13 @@ def main():
             out = torch.empty(B * Lq, H * hd, dtype=torch.bfloat16, device=dev)
             ms = timeit(lambda: ops.attention(q, k, None, H, hd, batch=B, out=out, v_prepared=vp), args.iters)
             tf = 4.0 * B * Lq * Lk * H * hd / ms / 1e9
-            res.append(dict(kernel="attention", tag=tag, H=H, hd=hd, B=B, Lq=Lq, Lk=Lk, ms=ms, tflops=tf, frac=tf / 2500))
+            res.append(dict(kernel="attention", variant=av, tag=tag, H=H, hd=hd, B=B, Lq=Lq, Lk=Lk, ms=ms, tflops=tf, frac=tf / 2500))
             print(f"attn {tag:14s} H={H:3d} hd={hd:3d} B={B:2d} Lq={Lq:6d} Lk={Lk:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s  {tf/25:5.1f}% of peak", flush=True)
             ms = timeit(lambda: ops.prepare_v(v, H, hd, B), args.iters)
             gb = 2.0 * v.numel() * 2 / ms / 1e6
             print(f"     v_transpose {tag:14s} {ms:8.3f} ms  {gb:7.1f} GB/s", flush=True)
             del q, k, v, vp, out
+      ops.set_option("attn_var", 0)
     if args.only in ("", "glue"):
         x = torch.randn(L, 5120, device=dev)
         sc = torch.randn(5120, device=dev)
