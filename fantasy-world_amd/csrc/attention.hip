@@ -255,6 +255,266 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong attention kernel.  Same tiling, LDS images and data layout as attention_kernel above, different schedule:
+// a 64-key tile is executed as FOUR segments separated by raw s_barriers,
+//     S1  read the K tile into registers (HD/8 ds_read_b128)           S3  read the Vt tile into the SAME registers + softmax
+//     S2  QK^T: HD/8 MFMAs (+ DMA of V(t+1))                           S4  PV: HD/8 MFMAs (+ DMA of K(t+2))
+// and the two 4-wave groups of the work-group (waves w and w+4 share a SIMD) run ONE segment apart, so on every SIMD one
+// wave is in a matrix segment (fragments already in registers: MFMAs issue back to back) while its partner is in an
+// LDS/VALU segment.  K and V time-share one fragment register block, the scores of only one tile are live.
+//     slot:        4t      4t+1    4t+2    4t+3    4t+4
+//     group A:   S1(t)   S2(t)   S3(t)   S4(t)   S1(t+1)
+//     group B:   S4(t-1) S1(t)   S2(t)   S3(t)   S4(t)
+// K ring slot t&1 is last read in slot 4t+1, V ring slot t&1 in slot 4t+3; K(t+2) is requested in S4(t) (slot >= 4t+3) and
+// first read in slot 4t+8, V(t+1) in S2(t) (slot >= 4t+1 > 4t-1) and first read in slot 4t+6.  Every wave issues 2 K and 2 V
+// DMA instructions per tile (for hd < 128 with part of the lanes masked), so the waits are counted:
+//     group A: end of S2(t): vmcnt(4) -> own V(t) landed;    end of S4(t): vmcnt(4) -> own K(t+1) landed
+//     group B: end of S1(t): vmcnt(2) -> own V(t) landed;    end of S3(t): vmcnt(2) -> own K(t+1) landed
+// each before the barrier that precedes the first read of that tile by any wave (vmcnt(0) on the last tiles).
+// VAR bit 0: s_setprio(1) around the matrix segments; bit 1: deferred rescale (the running max is only raised when it
+// grows by more than 2^8 in the exponent domain: P <= 256, exact in fp32/bf16 floating point, no extra error).
+// ---------------------------------------------------------------------------------------------------------------
+#define FW_ABARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <int N> __device__ __forceinline__ void fw_await_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int HD, int VAR>
+__global__ __launch_bounds__(512, 2) void attention_pp_kernel(AttnArgs p) {
+    constexpr bool PRIO = (VAR & 1) != 0, DEFER = (VAR & 2) != 0;
+    constexpr int KS = HD / 16;          // k-steps of the QK^T contraction
+    constexpr int DB = HD / 32;          // 32-row blocks of O^T
+    constexpr int NCH = HD / 8;          // valid 16-B chunks per K row
+    constexpr int NFR = HD / 8;          // fragments per tile: 2*KS (K) == 4*DB (Vt)
+    constexpr int VT_TILE_BYTES = HD * 128;
+    constexpr int VROWS = HD / 16;       // Vt rows per DMA instruction (16 instructions per tile, 2 per wave)
+    constexpr int VLANES = VROWS * 8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int fi = lane & 31, hi = lane >> 5;
+
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
+    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
+    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
+
+    const int q_row = qb * QB + wave * 32 + fi;
+    bf16x8_t qf[KS];
+    {
+        const int qr = min(q_row, p.Lq - 1);
+        const uint16_t* src = Qp + (int64_t)qr * p.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(src + ks * 16);
+    }
+
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+
+    // ---- DMA addressing: uniform tile base (SGPR) + per-lane unsigned byte offset -------------------------------------
+    // K tile: 16 pieces of 4 rows x 256 B; wave w issues pieces w and w+8.  lane -> row = 4*pc + lane/16, physical chunk
+    // = lane%16, logical chunk = phys ^ (row&15) (lanes whose logical chunk is beyond the head are masked off).
+    unsigned koff[2], koffl[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 8 * i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (row & 15);
+        kvalid[i] = chunk < NCH;
+        koff[i] = (unsigned)(row * (int)p.ldk + chunk * 8) * 2u;
+        const int rl = min(row, p.Lk - 1 - (nt - 1) * KVB);           // last (possibly ragged) tile: clamp to the last key
+        koffl[i] = (unsigned)(rl * (int)p.ldk + chunk * 8) * 2u;
+    }
+    // Vt tile: 16 instructions of VROWS rows x 128 B; wave w issues instructions 2w and 2w+1 (lanes >= VLANES masked off).
+    unsigned voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int d = min((wave * 2 + i) * VROWS + (lane >> 3), HD - 1);
+        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
+        voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
+    }
+    const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
+    auto issue_k = [&](int slot, int t) {
+        const char* kt = Kp + (size_t)t * k_tile_stride;
+        char* k_lds = smem + slot * K_TILE_BYTES;
+        const bool last = ragged && t == nt - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = last ? koffl[i] : koff[i];
+            if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + 8 * i) * 1024);
+        }
+    };
+    auto issue_v = [&](int slot, int t) {
+        const char* vt = Vp + (size_t)t * (KVB * 2);
+        char* v_lds = smem + 2 * K_TILE_BYTES + slot * VT_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave * 2 + i) * (VROWS * 128));
+    };
+
+    int kcoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
+    int vcoff[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) vcoff[s2] = 2 * K_TILE_BYTES + fi * 128 + (((2 * s2 + hi) ^ ((fi >> 1) & 7)) << 4);
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+    const float c = p.scale_log2;
+    bf16x8_t fr[NFR];
+    f32x16_t s0, s1;
+    uint32_t pw[16];
+
+    issue_k(0, 0);
+    issue_v(0, 0);
+    if (nt > 1) issue_k(1, 1);
+    fw_await_vm<0>();
+    FW_ABARRIER();
+    if (grp == 1) FW_ABARRIER();
+
+    for (int t = 0; t < nt; ++t) {
+        const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
+        // ------------------------------------------------------------ S1: K fragments -> registers
+        {
+            const char* kb = smem + (t & 1) * K_TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                fr[2 * ks] = *(const bf16x8_t*)(kb + kcoff[ks]);
+                fr[2 * ks + 1] = *(const bf16x8_t*)(kb + 32 * 256 + kcoff[ks]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) { if (has1) fw_await_vm<2>(); else fw_await_vm<0>(); }
+        FW_ABARRIER();
+        // ------------------------------------------------------------ S2: S^T = K Q^T (+ DMA of V(t+1))
+        if (has1) issue_v((t + 1) & 1, t + 1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) { if (has1) fw_await_vm<4>(); else fw_await_vm<0>(); }
+        FW_ABARRIER();
+        // ------------------------------------------------------------ S3: Vt fragments -> registers, online softmax
+        {
+            const char* vb = smem + (t & 1) * VT_TILE_BYTES;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) fr[s2 * DB + d] = *(const bf16x8_t*)(vb + d * 32 * 128 + vcoff[s2]);
+        }
+        if (ragged && t == nt - 1) {
+            const int kbase = t * KVB + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kbase + (r & 3) + 8 * (r >> 2);
+                if (kk >= p.Lk) s0[r] = -1.0e30f;
+                if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
+            }
+        }
+        {
+            float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const bool need = DEFER ? ((mx - m_run) * c > 8.0f) : (mx > m_run);
+            if (__any(need)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = m_run * c;
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+                const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
+                const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+                const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+                ls += (a0 + a1) + (b0 + b1);
+                pw[r >> 1] = pack_bf16x2(a0, a1);
+                pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
+            }
+            l_run += ls;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) { if (has1) fw_await_vm<2>(); else fw_await_vm<0>(); }
+        FW_ABARRIER();
+        // ------------------------------------------------------------ S4: O^T += Vt P^T (+ DMA of K(t+2))
+        if (has2) issue_k(t & 1, t + 2);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            u32x4_t pv4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+            bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+            for (int d = 0; d < DB; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s2 * DB + d], pf, o[d], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) { if (has2) fw_await_vm<4>(); else fw_await_vm<0>(); }
+        FW_ABARRIER();
+    }
+    if (grp == 0) FW_ABARRIER();
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l --------------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Lq) {
+        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * hi;
+                float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
+                float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
+                u32x2_t* ptr = (u32x2_t*)(dst + col);
+                if (p.accumulate) {
+                    const u32x2_t old = *ptr;
+                    v0 += __uint_as_float(old[0] << 16);
+                    v1 += __uint_as_float(old[0] & 0xffff0000u);
+                    v2 += __uint_as_float(old[1] << 16);
+                    v3 += __uint_as_float(old[1] & 0xffff0000u);
+                }
+                u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                *ptr = w;
+            }
+        }
+    }
+}
+
 // V[b][Lk][heads*hd] -> Vt[b][h][d][Lk_pad]; position p inside each 32-key block holds key swap_bits_2_3(p).
 // One work-group transposes a 64-key x 64-channel tile through LDS.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ V, int64_t ldv, int64_t bsv,
@@ -324,6 +584,18 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
+    const int var = fw_get_option(FW_OPT_ATTN_VAR);     // 0 = first kernel; 16 + bits = ping-pong kernel (bit 0 prio, bit 1 deferred rescale)
+    if (var >= 16) {
+#define FW_ATTN_PP(HDV, V) hipLaunchKernelGGL((attention_pp_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
+#define FW_ATTN_PP_HD(V) do { if (head_dim == 128) FW_ATTN_PP(128, V); else if (head_dim == 96) FW_ATTN_PP(96, V); else FW_ATTN_PP(64, V); } while (0)
+        switch (var & 3) {
+            case 0: FW_ATTN_PP_HD(0); break;
+            case 1: FW_ATTN_PP_HD(1); break;
+            case 2: FW_ATTN_PP_HD(2); break;
+            default: FW_ATTN_PP_HD(3); break;
+        }
+        return (int)hipGetLastError();
+    }
     if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3((unsigned)nwg), dim3(512), 0, st, p);
     else if (head_dim == 96) hipLaunchKernelGGL(attention_kernel<96>, dim3((unsigned)nwg), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(attention_kernel<64>, dim3((unsigned)nwg), dim3(512), 0, st, p);

@@ -154,6 +154,16 @@ def test_gemv_f32(ops, ref):
 
 
 # --------------------------------------------------------------------------------------------------------- attention
+DEFAULT_ATTN_VAR = 0
+
+
+@pytest.fixture(params=[0, 17, 19], ids=["attn_v0", "attn_pp_prio", "attn_pp_prio_defer"])
+def attn_variant(ops, request):
+    """Every attention test runs on the first kernel (0) and on the ping-pong kernel (16 + schedule bits)."""
+    ops.set_option("attn_var", request.param)
+    yield request.param
+    ops.set_option("attn_var", DEFAULT_ATTN_VAR)
+
 ATTN_CASES = [  # heads, hd, batch, Lq, Lk
     (3, 128, 1, 300, 333), (2, 128, 1, 64, 64), (5, 128, 1, 1000, 257), (2, 128, 1, 257, 512),
     (4, 96, 1, 290, 305), (12, 96, 1, 48, 63), (3, 64, 1, 500, 129), (16, 64, 3, 133, 133), (2, 64, 2, 31, 1),
@@ -161,14 +171,14 @@ ATTN_CASES = [  # heads, hd, batch, Lq, Lk
 
 
 @pytest.mark.parametrize("heads,hd,batch,Lq,Lk", ATTN_CASES)
-def test_attention_matches_softmax_reference(ops, ref, heads, hd, batch, Lq, Lk):
+def test_attention_matches_softmax_reference(attn_variant, ops, ref, heads, hd, batch, Lq, Lk):
     q, k, v = rnd(batch * Lq, heads * hd, seed=1), rnd(batch * Lk, heads * hd, seed=2), rnd(batch * Lk, heads * hd, seed=3)
     want = ref.attention(q, k, v, heads, hd, batch=batch)
     got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, batch=batch)
     assert rel_l2(got.float(), want) < 4e-3
 
 
-def test_attention_strided_qkv_and_accumulate(ops, ref):
+def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref):
     """q/k/v as column slices of one fused buffer; second call accumulates (cross-attn text + image, DIT21:197-200)."""
     heads, hd, L, Lc = 4, 128, 200, 77
     D = heads * hd
@@ -184,7 +194,7 @@ def test_attention_strided_qkv_and_accumulate(ops, ref):
     assert rel_l2(got.float(), want2) < 5e-3
 
 
-def test_attention_large_score_spike(ops, ref):
+def test_attention_large_score_spike(attn_variant, ops, ref):
     """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence."""
     heads, hd, Lq, Lk = 1, 128, 64, 640
     q, k, v = rnd(Lq, hd, seed=6), rnd(Lk, hd, seed=7), rnd(Lk, hd, seed=8)
@@ -197,7 +207,7 @@ def test_attention_large_score_spike(ops, ref):
     assert torch.isfinite(got.float()).all()
 
 
-def test_attention_full_length_properties(ops):
+def test_attention_full_length_properties(attn_variant, ops):
     """BASELINE config-2 size (L = 32760, hd 128): rows of softmax sum to 1 => V = const gives O = const, and
     sampled query rows match an fp32 evaluation of the same rows."""
     heads, hd, L = 2, 128, 32760
@@ -217,7 +227,7 @@ def test_attention_full_length_properties(ops):
         assert rel_l2(o[rows][:, sl].float(), want) < 6e-3
 
 
-def test_attention_rejects_bad_head_dim(ops):
+def test_attention_rejects_bad_head_dim(attn_variant, ops):
     q = torch.zeros(8, 80, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError):
         ops.attention(q, q, q, 1, 80)
