@@ -16,6 +16,7 @@
 // barrier per tile.  The loop is software pipelined: K runs one tile ahead of V, and the QK^T MFMAs of tile t+1 are
 // issued between the row-max and the exponentials of tile t, so matrix and vector work of one wave overlap.  Work-groups are ordered so that one XCD works on one head at a time (K/V stay in its L2).
 #include "fw_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -515,6 +516,639 @@ __global__ __launch_bounds__(512, 2) void attention_pp_kernel(AttnArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ping-pong attention, TWO segments per tile (the schedule the PMC counters asked for).
+//
+// Measured on attention_pp_kernel (rocprofv3 PMC, profiles/r01): ~226 VALU instructions and ~1400 active cycles per
+// wave-tile against 1024 cycles of MFMA; with four segments per tile the softmax segment (~1400 cycles) was paired with a
+// 512-cycle matrix segment twice per tile, i.e. tile time = 1024 + 2 x 1400: VALU and MFMA time ADD instead of overlapping
+// (53 % matrix-pipe utilisation at the real 1.9 GHz clock).  Here a wave alternates only two segments,
+//     V(t)   read the Vt(t) tile into the fragment registers, online softmax of tile t            (LDS + VALU)
+//     MM(t)  PV(t): HD/8 MFMAs, each followed by the ds_read of one K(t+1) fragment into the register the MFMA just
+//            released; then QK^T(t+1): HD/8 MFMAs; DMA of K(t+4) and V(t+3) issued from inside   (matrix pipe)
+// and the two 4-wave groups run one segment apart, so a SIMD always has one wave in V and one in MM:
+//     slot:       2t      2t+1     2t+2
+//     group A:   V(t)    MM(t)    V(t+1)          tile time = 2 x max(V, MM) instead of 2 x V + MM, two barriers per tile
+//     group B:   MM(t-1) V(t)     MM(t)
+// K and Vt tiles live in 4-deep LDS rings (the kernel is register-bound to one work-group per CU, so all 128 KiB are free):
+// K(t) is last read in slot 2t, V(t) in slot 2t+1; K(t+4) / V(t+3) are requested in MM(t) (slot >= 2t+1) and first read in
+// slots 2t+7 / 2t+6, i.e. ~3 tile times ahead.  Per-wave DMA order is K(0) | K(1) V(0) | K(2) V(1) | ..., 2 instructions
+// each, and the waits are counted:  group A: end of V(t): vmcnt(10) -> own K(t+1); end of MM(t): vmcnt(8) -> own V(t+1)
+//                                   group B: end of V(t): vmcnt(4)  -> own V(t+1); end of MM(t): vmcnt(10) -> own K(t+2)
+// (vmcnt(0) on the last four tiles).  Rescale of O is deferred until the running max grows by more than 2^8 (exact in
+// floating point: P <= 256).  VAR bit 0: s_setprio(1) around MM.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fw_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// max of the 16 values of an accumulator: 7 v_max3 + 1 v_max in ONE asm statement (no per-op canonicalisation, one boundary pad)
+__device__ __forceinline__ float fw_max16(const f32x16_t& v) {
+    float r, t;
+    asm("v_max3_f32 %0, %2, %3, %4\n\t"
+        "v_max3_f32 %1, %5, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %1, %1, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %1, %1, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17\n\t"
+        "v_max_f32 %0, %0, %1"
+        : "=&v"(r), "=&v"(t)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    return r;
+}
+
+constexpr int ARING = 4;
+
+// segment timestamps of work-group 0 at tile 100 (attention_pp3_kernel<.., VAR & 2>): [wave][8] shader-clock ticks
+__device__ unsigned long long g_attn_ts[8 * 8];
+#define FW_TS(K) do { if (TIMING && blockIdx.x == 0 && t == 100 && lane == 0) g_attn_ts[wave * 8 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <int HD, int VAR>
+__global__ __launch_bounds__(512, 2) void attention_pp2_kernel(AttnArgs p) {
+    constexpr bool PRIO = (VAR & 1) != 0, PIN = (VAR & 2) != 0;
+    constexpr bool DMA_V = (VAR & 4) != 0;    // issue the tile DMA from the V segment (K(t+3), V(t+3)) instead of from MM (K(t+4), V(t+3))
+    constexpr bool DMA_QK = (VAR & 8) != 0;   // issue it between the QK^T MFMAs instead of in front of the PV MFMAs
+    constexpr int KS = HD / 16, DB = HD / 32, NCH = HD / 8, NFR = HD / 8;
+    constexpr int VT_TILE_BYTES = HD * 128;
+    constexpr int VROWS = HD / 16, VLANES = VROWS * 8;
+    constexpr int V_BASE = ARING * K_TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[ARING * K_TILE_BYTES + ARING * VT_TILE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int fi = lane & 31, hi = lane >> 5;
+
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
+    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
+    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
+
+    const int q_row = qb * QB + wave * 32 + fi;
+    bf16x8_t qf[KS];
+    {
+        const int qr = min(q_row, p.Lq - 1);
+        const uint16_t* src = Qp + (int64_t)qr * p.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(src + ks * 16);
+    }
+
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+
+    unsigned koff[2], koffl[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 8 * i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (row & 15);
+        kvalid[i] = chunk < NCH;
+        koff[i] = (unsigned)(row * (int)p.ldk + chunk * 8) * 2u;
+        const int rl = min(row, p.Lk - 1 - (nt - 1) * KVB);
+        koffl[i] = (unsigned)(rl * (int)p.ldk + chunk * 8) * 2u;
+    }
+    unsigned voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int d = min((wave * 2 + i) * VROWS + (lane >> 3), HD - 1);
+        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
+        voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
+    }
+    const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
+    auto issue_k = [&](int t) {                 // K(t) -> ring slot t & 3 (2 DMA instructions per wave)
+        const char* kt = Kp + (size_t)t * k_tile_stride;
+        char* k_lds = smem + (t & (ARING - 1)) * K_TILE_BYTES;
+        const bool last = ragged && t == nt - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = last ? koffl[i] : koff[i];
+            if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + 8 * i) * 1024);
+        }
+    };
+    auto issue_v = [&](int t) {                 // Vt(t) -> ring slot t & 3 (2 DMA instructions per wave)
+        const char* vt = Vp + (size_t)t * (KVB * 2);
+        char* v_lds = smem + V_BASE + (t & (ARING - 1)) * VT_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave * 2 + i) * (VROWS * 128));
+    };
+
+    int kcoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
+    int vcoff[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) vcoff[s2] = V_BASE + fi * 128 + (((2 * s2 + hi) ^ ((fi >> 1) & 7)) << 4);
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+    const float c = p.scale_log2;
+    bf16x8_t fr[NFR];
+    f32x16_t s0, s1;
+    uint32_t pw[16];
+
+    // ---- prologue: K(0) | K(1) V(0) | K(2) V(1) | K(3) V(2), then S(0) = K(0) Q^T by every wave ------------------------
+    issue_k(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j + 1 < nt && (!DMA_V || j < 2)) issue_k(j + 1);
+        if (j < nt) issue_v(j);
+    }
+    fw_await_vm<0>();
+    FW_ABARRIER();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        fr[2 * ks] = *(const bf16x8_t*)(smem + kcoff[ks]);
+        fr[2 * ks + 1] = *(const bf16x8_t*)(smem + 32 * 256 + kcoff[ks]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+    }
+    if (grp == 1) FW_ABARRIER();
+
+    int t = 0;
+    auto tile = [&](auto has1_tag) {
+        constexpr bool has1 = decltype(has1_tag)::value;
+        const bool steady = DMA_V ? (t + 3 < nt) : (t + 4 < nt);
+        // ------------------------------------------------------------ V(t): Vt fragments -> registers, online softmax
+        {
+            const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int d = 0; d < DB; ++d) fr[s2 * DB + d] = *(const bf16x8_t*)(vb + d * 32 * 128 + vcoff[s2]);
+        }
+        if (DMA_V && t + 3 < nt) { issue_k(t + 3); issue_v(t + 3); }
+        if (ragged && t == nt - 1) {
+            const int kbase = t * KVB + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kbase + (r & 3) + 8 * (r >> 2);
+                if (kk >= p.Lk) s0[r] = -1.0e30f;
+                if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
+            }
+        }
+        {
+            float mx = fw_max16(s0);
+            mx = fmaxf(mx, fw_max16(s1));
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            if (__any((mx - m_run) * c > 8.0f)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                m_run = m_new;
+            }
+            const float mc = m_run * c;
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+                const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
+                const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+                const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
+                ls += (a0 + a1) + (b0 + b1);
+                pw[r >> 1] = pack_bf16x2(a0, a1);
+                pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
+            }
+            l_run += ls;
+        }
+        if (PIN) {   // keep the exponentials and the row sum in THIS segment (LLVM otherwise sinks them behind the barrier, next to
+                     // the PV MFMAs, and keeps all 32 probabilities alive for a serial add chain at the end of MM)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pw[i]));
+            asm volatile("" : "+v"(l_run));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!steady) fw_await_vm<0>();
+        else if (DMA_V) { if (grp == 0) fw_await_vm<10>(); else fw_await_vm<8>(); }
+        else { if (grp == 0) fw_await_vm<10>(); else fw_await_vm<4>(); }
+        FW_ABARRIER();
+        // ------------------------------------------------------------ MM(t): PV(t), K(t+1) fragments, QK^T(t+1)
+        if (!DMA_V && !DMA_QK) {
+            if (t + 4 < nt) issue_k(t + 4);
+            if (t + 3 < nt) issue_v(t + 3);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        const char* kb = smem + ((t + 1) & (ARING - 1)) * K_TILE_BYTES;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            u32x4_t pv4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+            bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int i = s2 * DB + d;
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf, o[d], 0, 0, 0);
+                // fragment register i is free now: refill it with K(t+1) fragment i (key block i&1, k-step i>>1)
+                if (has1) fr[i] = *(const bf16x8_t*)(kb + (i & 1) * 32 * 256 + kcoff[i >> 1]);
+            }
+        }
+        if (has1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+                if (DMA_QK && !DMA_V) {
+                    if (ks == 0 && t + 4 < nt) issue_k(t + 4);
+                    if (ks == KS / 2 && t + 3 < nt) issue_v(t + 3);
+                }
+            }
+        }
+        if (has1 && !(DMA_QK && !DMA_V)) {
+            // pin the issue order: PV MFMA i, then the ds_read that refills its fragment register, ..., then the QK^T MFMAs
+            // (left alone, the scheduler postpones every read behind the 16 PV MFMAs and then waits on each pair)
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NFR, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!steady) fw_await_vm<0>();
+        else if (DMA_V) { if (grp == 0) fw_await_vm<8>(); else fw_await_vm<6>(); }
+        else { if (grp == 0) fw_await_vm<8>(); else fw_await_vm<10>(); }
+        FW_ABARRIER();
+    };
+    for (; t < nt - 1; ++t) tile(std::true_type{});
+    tile(std::false_type{});
+    if (grp == 0) FW_ABARRIER();
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Lq) {
+        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * hi;
+                float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
+                float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
+                u32x2_t* ptr = (u32x2_t*)(dst + col);
+                if (p.accumulate) {
+                    const u32x2_t old = *ptr;
+                    v0 += __uint_as_float(old[0] << 16);
+                    v1 += __uint_as_float(old[0] & 0xffff0000u);
+                    v2 += __uint_as_float(old[1] << 16);
+                    v3 += __uint_as_float(old[1] & 0xffff0000u);
+                }
+                u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                *ptr = w;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention_pp3_kernel: the two-segment ping-pong schedule of attention_pp2_kernel with the softmax cut down to what the
+// issue slots allow.  Measured (pp2 variants, hd 128 vs 64): slot time ~ V-segment + 0.8 x MM-segment, i.e. VALU work of
+// one wave hardly overlaps the MFMAs of its SIMD partner -- every instruction of either wave costs an issue slot of the
+// shared SIMD, so the lever is the instruction COUNT per tile.  Requires FW_ATTN_Q_PRESCALED (scores arrive in the log2
+// domain).  Per 64-key tile and lane:
+//   * the running max is folded into QK^T: the first MFMA of a score block takes C = splat(-m_run) (a 16-register block that
+//     changes only on a rescale) instead of 0, so the accumulator already holds s - m_run: no multiply-add per score;
+//   * no per-tile max: P = exp2(s - m_run) is computed directly, and only if a half-row sum exceeds 2^14 (some P >= 2^8; also
+//     catches inf/NaN) -- or on the very first tile -- does the wave take the slow path: exact max, m_run += max, rescale O and
+//     l, shift the scores, recompute P.  P stays <= 2^14: exact in fp32/bf16 floating point, no accuracy cost.
+//   fast path: 32 v_exp + 31 v_add + 16 v_cvt_pk + 1 compare  (vs ~160 VALU before).
+// VAR bit 0: DMA issued between the QK^T MFMAs (else in front of the PV MFMAs).
+// ---------------------------------------------------------------------------------------------------------------
+template <int HD, int VAR>
+__global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
+    constexpr bool DMA_QK = (VAR & 1) != 0;
+    constexpr bool TIMING = (VAR & 2) != 0;    // measurement build: s_memtime at the segment boundaries of one tile
+    constexpr int KS = HD / 16, DB = HD / 32, NCH = HD / 8, NFR = HD / 8;
+    constexpr int VT_TILE_BYTES = HD * 128;
+    constexpr int VROWS = HD / 16, VLANES = VROWS * 8;
+    constexpr int V_BASE = ARING * K_TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[ARING * K_TILE_BYTES + ARING * VT_TILE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int fi = lane & 31, hi = lane >> 5;
+
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
+    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
+    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
+
+    const int q_row = qb * QB + wave * 32 + fi;
+    bf16x8_t qf[KS];
+    {
+        const int qr = min(q_row, p.Lq - 1);
+        const uint16_t* src = Qp + (int64_t)qr * p.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(src + ks * 16);
+    }
+
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+
+    unsigned koff[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 8 * i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (row & 15);
+        kvalid[i] = chunk < NCH;
+        koff[i] = (unsigned)(row * (int)p.ldk + chunk * 8) * 2u;
+    }
+    unsigned voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int d = min((wave * 2 + i) * VROWS + (lane >> 3), HD - 1);
+        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
+        voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
+    }
+    const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
+    auto issue_k = [&](int t) {
+        const char* kt = Kp + (size_t)t * k_tile_stride;
+        char* k_lds = smem + (t & (ARING - 1)) * K_TILE_BYTES;
+        const bool last = ragged && t == nt - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned off = koff[i];
+            if (last) {     // ragged last tile: rows beyond the last key re-read the last key (their scores are masked)
+                const int row = (wave + 8 * i) * 4 + (lane >> 4);
+                const int over = row - (p.Lk - 1 - (nt - 1) * KVB);
+                if (over > 0) off -= (unsigned)(over * (int)p.ldk) * 2u;
+            }
+            if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + 8 * i) * 1024);
+        }
+    };
+    auto issue_v = [&](int t) {
+        const char* vt = Vp + (size_t)t * (KVB * 2);
+        char* v_lds = smem + V_BASE + (t & (ARING - 1)) * VT_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave * 2 + i) * (VROWS * 128));
+    };
+
+    int kcoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
+    int vcoff[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) vcoff[s2] = V_BASE + fi * 128 + (((2 * s2 + hi) ^ ((fi >> 1) & 7)) << 4);
+
+    f32x16_t o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;       // m_run: shift already folded into the scores (log2 domain)
+    f32x16_t negm;                        // splat(-m_run): accumulator input of the first QK^T MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    bf16x8_t fr[NFR];
+    f32x16_t s0, s1;
+    uint32_t pw[16];
+
+    issue_k(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j + 1 < nt) issue_k(j + 1);
+        if (j < nt) issue_v(j);
+    }
+    fw_await_vm<0>();
+    FW_ABARRIER();
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        fr[2 * ks] = *(const bf16x8_t*)(smem + kcoff[ks]);
+        fr[2 * ks + 1] = *(const bf16x8_t*)(smem + 32 * 256 + kcoff[ks]);
+    }
+    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0], qf[0], negm, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1], qf[0], negm, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+    }
+    if (grp == 1) FW_ABARRIER();
+
+    int t = 0;
+    auto tile = [&](auto has1_tag) {
+        constexpr bool has1 = decltype(has1_tag)::value;
+        const bool steady = t + 4 < nt;
+        // ------------------------------------------------------------ V(t): Vt fragments -> registers, softmax
+        FW_TS(0);
+        {
+            const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)       // first half of the Vt fragments; the rest is fetched behind the first PV MFMAs
+#pragma unroll
+                for (int d = 0; d < DB; ++d) fr[s2 * DB + d] = *(const bf16x8_t*)(vb + d * 32 * 128 + vcoff[s2]);
+        }
+        if (ragged && t == nt - 1) {
+            const int kbase = t * KVB + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = kbase + (r & 3) + 8 * (r >> 2);
+                if (kk >= p.Lk) s0[r] = -1.0e30f;
+                if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
+            }
+        }
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float a0 = __builtin_amdgcn_exp2f(s0[r]), a1 = __builtin_amdgcn_exp2f(s0[r + 1]);
+            const float b0 = __builtin_amdgcn_exp2f(s1[r]), b1 = __builtin_amdgcn_exp2f(s1[r + 1]);
+            ls += (a0 + a1) + (b0 + b1);
+            pw[r >> 1] = pack_bf16x2(a0, a1);
+            pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
+        }
+        if (__any(t == 0 || !(ls <= 16384.0f))) {
+            // slow path (first tile, or some probability of this tile left the safe range): exact tile max, move the running max
+            float mx = fmaxf(fw_max16(s0), fw_max16(s1));
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);      // later tiles only ever raise the max
+            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // nothing accumulated yet on tile 0
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+            ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float a0 = __builtin_amdgcn_exp2f(s0[r] - delta), a1 = __builtin_amdgcn_exp2f(s0[r + 1] - delta);
+                const float b0 = __builtin_amdgcn_exp2f(s1[r] - delta), b1 = __builtin_amdgcn_exp2f(s1[r + 1] - delta);
+                ls += (a0 + a1) + (b0 + b1);
+                pw[r >> 1] = pack_bf16x2(a0, a1);
+                pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
+            }
+        }
+        l_run += ls;
+        {   // keep the softmax in THIS segment (LLVM otherwise sinks it behind the barrier, next to the PV MFMAs)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pw[i]));
+            asm volatile("" : "+v"(l_run));
+        }
+        FW_TS(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!steady) fw_await_vm<0>();
+        else if (grp == 0) fw_await_vm<10>();
+        else fw_await_vm<4>();
+        FW_TS(2);
+        FW_ABARRIER();
+        FW_TS(3);
+        // ------------------------------------------------------------ MM(t): PV(t), K(t+1) fragments, QK^T(t+1)
+        if (!DMA_QK) {
+            if (t + 4 < nt) issue_k(t + 4);
+            if (t + 3 < nt) issue_v(t + 3);
+        }
+        const char* kb = smem + ((t + 1) & (ARING - 1)) * K_TILE_BYTES;
+        const char* vb2 = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+        constexpr int HF = NFR / 2;
+        // fragment register block fr[0..NFR): every MFMA is followed by the ds_read that refills a register it (or an earlier
+        // MFMA) released, >= HF MFMAs ahead of its consumer:
+        //   PV  s2 = 0,1  (fr[0..HF))   + reads Vt fragments HF..NFR   -> fr[HF..NFR)
+        //   PV  s2 = 2,3  (fr[HF..NFR)) + reads K(t+1) fragments 0..HF  -> fr[0..HF)
+        //   QK  ks < KS/2 (fr[0..HF))   + reads K(t+1) fragments HF..NFR -> fr[HF..NFR)
+        //   QK  ks >= KS/2 (fr[HF..NFR))
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            u32x4_t pv4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
+            bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int i = s2 * DB + d;
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf, o[d], 0, 0, 0);
+                if (i < HF) {
+                    const int j = HF + i;              // Vt fragment j = (s2' = j / DB, d' = j % DB)
+                    fr[j] = *(const bf16x8_t*)(vb2 + (j % DB) * 32 * 128 + vcoff[j / DB]);
+                } else if (has1) {
+                    const int j = i - HF;              // K(t+1) fragment j = (key block j & 1, k-step j >> 1)
+                    fr[j] = *(const bf16x8_t*)(kb + (j & 1) * 32 * 256 + kcoff[j >> 1]);
+                }
+            }
+        }
+        if (has1) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks == 0) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0], qf[0], negm, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[1], qf[0], negm, 0, 0, 0);
+                } else {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+                }
+                if (ks < KS / 2) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = HF + 2 * ks + e;
+                        fr[j] = *(const bf16x8_t*)(kb + (j & 1) * 32 * 256 + kcoff[j >> 1]);
+                    }
+                }
+                if (DMA_QK) {
+                    if (ks == KS / 2 && t + 4 < nt) issue_k(t + 4);
+                    if (ks == KS / 2 + 1 && t + 3 < nt) issue_v(t + 3);
+                }
+            }
+            // pin the issue order: MFMA, ds_read, MFMA, ds_read, ...
+#pragma unroll
+            for (int i = 0; i < NFR + HF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if (!DMA_QK) __builtin_amdgcn_sched_group_barrier(0x008, HF, 0);
+        }
+        FW_TS(4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!steady) fw_await_vm<0>();
+        else if (grp == 0) fw_await_vm<8>();
+        else fw_await_vm<10>();
+        FW_TS(5);
+        FW_ABARRIER();
+        FW_TS(6);
+    };
+    for (; t < nt - 1; ++t) tile(std::true_type{});
+    tile(std::false_type{});
+    if (grp == 0) FW_ABARRIER();
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Lq) {
+        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * hi;
+                float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
+                float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
+                u32x2_t* ptr = (u32x2_t*)(dst + col);
+                if (p.accumulate) {
+                    const u32x2_t old = *ptr;
+                    v0 += __uint_as_float(old[0] << 16);
+                    v1 += __uint_as_float(old[0] & 0xffff0000u);
+                    v2 += __uint_as_float(old[1] << 16);
+                    v3 += __uint_as_float(old[1] & 0xffff0000u);
+                }
+                u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                *ptr = w;
+            }
+        }
+    }
+}
+
 // V[b][Lk][heads*hd] -> Vt[b][h][d][Lk_pad]; position p inside each 32-key block holds key swap_bits_2_3(p).
 // One work-group transposes a 64-key x 64-channel tile through LDS.
 __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ V, int64_t ldv, int64_t bsv,
@@ -569,7 +1203,7 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
                                  const uint16_t* Vt, int64_t Lk_pad,
                                  uint16_t* O, int64_t ldo, int64_t bso,
                                  int batch, int heads, int head_dim, int Lq, int Lk,
-                                 float scale, int accumulate, void* stream) {
+                                 float scale, int flags, void* stream) {
     if (batch <= 0 || heads <= 0 || Lq <= 0) return 0;
     if (Lk <= 0) { fw_set_error("fw_attention_bf16: Lk must be > 0"); return FW_E_BADARG; }
     if (head_dim != 64 && head_dim != 96 && head_dim != 128) { fw_set_error("fw_attention_bf16: head_dim must be 64, 96 or 128"); return FW_E_UNSUPPORTED; }
@@ -579,12 +1213,33 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     AttnArgs p;
     p.Q = Q; p.ldq = ldq; p.bsq = bsq; p.K = K; p.ldk = ldk; p.bsk = bsk; p.Vt = Vt; p.lkp = Lk_pad;
     p.O = O; p.ldo = ldo; p.bso = bso; p.batch = batch; p.heads = heads; p.Lq = Lq; p.Lk = Lk;
-    p.scale_log2 = scale * 1.4426950408889634f; p.accumulate = accumulate;
+    const bool prescaled = (flags & FW_ATTN_Q_PRESCALED) != 0;
+    p.scale_log2 = prescaled ? 1.0f : scale * 1.4426950408889634f; p.accumulate = (flags & FW_ATTN_ACCUMULATE) ? 1 : 0;
     p.nqb = (Lq + QB - 1) / QB;
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
     const int var = fw_get_option(FW_OPT_ATTN_VAR);     // 0 = first kernel; 16 + bits = ping-pong kernel (bit 0 prio, bit 1 deferred rescale)
+    if (prescaled && var >= 64) {
+        // fast path: log2-domain scores (var 64: DMA in front of PV, 65: DMA between the QK^T MFMAs)
+#define FW_ATTN_PP3(HDV, V) hipLaunchKernelGGL((attention_pp3_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
+        if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
+        else if (var & 1) { if (head_dim == 128) FW_ATTN_PP3(128, 1); else if (head_dim == 96) FW_ATTN_PP3(96, 1); else FW_ATTN_PP3(64, 1); }
+        else { if (head_dim == 128) FW_ATTN_PP3(128, 0); else if (head_dim == 96) FW_ATTN_PP3(96, 0); else FW_ATTN_PP3(64, 0); }
+        return (int)hipGetLastError();
+    }
+    if (var >= 32) {
+#define FW_ATTN_PP2(HDV, V) hipLaunchKernelGGL((attention_pp2_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
+#define FW_ATTN_PP2_HD(V) do { if (head_dim == 128) FW_ATTN_PP2(128, V); else if (head_dim == 96) FW_ATTN_PP2(96, V); else FW_ATTN_PP2(64, V); } while (0)
+        switch (var & 15) {
+            case 3: FW_ATTN_PP2_HD(3); break;
+            case 6: FW_ATTN_PP2_HD(6); break;
+            case 7: FW_ATTN_PP2_HD(7); break;
+            case 10: FW_ATTN_PP2_HD(10); break;
+            default: FW_ATTN_PP2_HD(2); break;
+        }
+        return (int)hipGetLastError();
+    }
     if (var >= 16) {
 #define FW_ATTN_PP(HDV, V) hipLaunchKernelGGL((attention_pp_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
 #define FW_ATTN_PP_HD(V) do { if (head_dim == 128) FW_ATTN_PP(128, V); else if (head_dim == 96) FW_ATTN_PP(96, V); else FW_ATTN_PP(64, V); } while (0)
@@ -611,4 +1266,10 @@ extern "C" int fw_v_transpose(const uint16_t* V, int64_t ldv, int64_t bsv, uint1
     dim3 grid((unsigned)(Lk_pad / 64), (unsigned)((width + 63) / 64), (unsigned)batch);
     hipLaunchKernelGGL(v_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, ldv, bsv, Vt, Lk_pad, heads, head_dim, Lk);
     return (int)hipGetLastError();
+}
+
+// Measurement hook (tools/attn_timeline.py): copies the segment timestamps written by the TIMING build of the ping-pong kernel.
+extern "C" int fw_debug_attention_timestamps(unsigned long long* host_out, int n) {
+    if (n <= 0 || n > 64) { fw_set_error("fw_debug_attention_timestamps: n must be in 1..64"); return FW_E_BADARG; }
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_ts), sizeof(unsigned long long) * n);
 }

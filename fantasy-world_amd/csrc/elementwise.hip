@@ -149,7 +149,7 @@ constexpr int QK_MAXW = 6144;
 
 __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, int64_t ldx, int heads, int hd,
                                                       int norm_mode, const float* __restrict__ nw, const float* __restrict__ nb,
-                                                      float eps, int rope_mode, const float* __restrict__ tab, int tab_rows) {
+                                                      float eps, int rope_mode, const float* __restrict__ tab, int tab_rows, float oscale) {
     __shared__ float rowbuf[QK_MAXW];
     __shared__ float red[4];
     const int row = blockIdx.x;
@@ -208,6 +208,12 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                 for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * r * nw[d0 + j] + nb[d0 + j];
             }
         }
+    }
+    if (oscale != 1.0f) {      // rotations are linear: scaling the normalised row scales the result
+#pragma unroll
+        for (int i = 0; i < QK_MAXC; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] *= oscale;
     }
     if (rope_mode == FW_ROPE_NONE) {
 #pragma unroll
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
 template <int CPL, int NORM, int ROPE>
 __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int heads, int hd,
                                                            const float* __restrict__ nw, const float* __restrict__ nb, float eps,
-                                                           const float* __restrict__ tab, int tab_rows) {
+                                                           const float* __restrict__ tab, int tab_rows, float oscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -346,6 +352,12 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             }
         }
     }
+    if (oscale != 1.0f) {      // rotations are linear: scaling the normalised row scales the result
+#pragma unroll
+        for (int i = 0; i < CPL; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] *= oscale;
+    }
     const float* trow = (ROPE != FW_ROPE_NONE) ? tab + (int64_t)(row % tab_rows) * hd : nullptr;   // [hd/2][2]
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -385,9 +397,9 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
 
 template <int CPL>
 static bool launch_qk_wave(hipStream_t st, uint16_t* x, int64_t ldx, int rows, int heads, int hd, int norm, const float* nw,
-                           const float* nb, float eps, int rope, const float* tab, int tab_rows) {
+                           const float* nb, float eps, int rope, const float* tab, int tab_rows, float oscale) {
     const dim3 grid((rows + 3) / 4), block(256);
-#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows); return true; }
+#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale); return true; }
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_INTERLEAVED)
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_NONE)
     FW_QK_CASE(FW_NORM_NONE, FW_ROPE_INTERLEAVED)
@@ -508,7 +520,8 @@ extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_
 }
 
 extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
-                          const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, void* stream) {
+                          const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                          void* stream) {
     if (rows <= 0) return 0;
     const int width = heads * head_dim;
     if (width > QK_MAXW || (head_dim % 8) || (ldx % 8) || (((uintptr_t)x) & 15)) { fw_set_error("fw_qk_prep: width <= 6144, head_dim % 8 == 0, 16-B alignment required"); return FW_E_BADARG; }
@@ -524,14 +537,14 @@ extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int hea
             const int cpl = (width / 8 + 63) / 64;
             hipStream_t st = (hipStream_t)stream;
             bool ok = false;
-            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
-            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
-            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
+            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
+            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
+            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
             if (ok) return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL(qk_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, heads, head_dim, norm_mode,
-                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows);
+                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
     return (int)hipGetLastError();
 }
 

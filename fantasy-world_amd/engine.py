@@ -198,24 +198,26 @@ class FusionEngine:
         qkv = ops.linear(xn, blk.qkv)
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         tab = tabs["dit"] if sh is None else tabs["dit_local"]
-        ops.qk_prep(q, H, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab)
+        # softmax_scale * log2(e) is folded into q before its bf16 rounding: attention then works in the log2 domain
+        ops.qk_prep(q, H, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
+                    out_scale=ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab)
         if sh is not None:
             kv = sh.all_gather_rows(qkv[:, D:], sh.dit_counts)   # [L, 2D] (k | v) of every rank
             k, v = kv[:, :D], kv[:, D:]
-        o = ops.attention(q, k, v, H, hd)
+        o = ops.attention(q, k, v, H, hd, q_prescaled=True)
         ops.linear(o, blk.o, g1=mod[2], res=x, out_f32=True, out=x)
         # cross-attention: text + image keys share q; outputs are summed (wan_video_dit.py:185-201)
         xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
         qc = ops.linear(xn3, blk.cq)
-        ops.qk_prep(qc, H, hd, norm="rms_full", norm_w=blk.cnorm_q, eps=cfg.eps)
+        ops.qk_prep(qc, H, hd, norm="rms_full", norm_w=blk.cnorm_q, eps=cfg.eps, out_scale=ops.q_scale(hd))
         kv = ops.linear(ctx_txt, blk.ckv)
         ops.qk_prep(kv[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k, eps=cfg.eps)
-        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd)
+        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd, q_prescaled=True)
         if ctx_img is not None:
             kvi = ops.linear(ctx_img, blk.ckv_img)
             ops.qk_prep(kvi[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k_img, eps=cfg.eps)
-            ops.attention(qc, kvi[:, :D], kvi[:, D:], H, hd, out=oc, accumulate=True)
+            ops.attention(qc, kvi[:, :D], kvi[:, D:], H, hd, out=oc, accumulate=True, q_prescaled=True)
         if blk.adapter and plucker is not None:
             # camera_control.py:109-127 ('adaln'): scale == 0 identically, so x <- x + shift
             t1 = ops.linear(oc, blk.a_g20, act="relu")
@@ -243,13 +245,13 @@ class FusionEngine:
         qkv = ops.linear(xn, blk.qkv)
         q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
         ops.qk_prep(q, H, hd, norm="ln_head", norm_w=blk.q_norm[0], norm_b=blk.q_norm[1], eps=cfg.vggt_eps,
-                    rope="half2d", table=tabs["vggt"])
+                    rope="half2d", table=tabs["vggt"], out_scale=ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="ln_head", norm_w=blk.k_norm[0], norm_b=blk.k_norm[1], eps=cfg.vggt_eps,
                     rope="half2d", table=tabs["vggt"])
         if not frame_mode and sh is not None:
             kv = sh.all_gather_rows(qkv[:, C:], sh.agg_counts)
             k, v = kv[:, :C], kv[:, C:]
-        o = ops.attention(q, k, v, H, hd, batch=batch)
+        o = ops.attention(q, k, v, H, hd, batch=batch, q_prescaled=True)
         ops.linear(o, blk.proj, g1=blk.ls1, res=tok, out_f32=True, out=tok)
         return e
 
@@ -272,7 +274,9 @@ class FusionEngine:
         b = ops.layernorm(tok, eps=1e-6)
         qv1 = ops.linear(a, bc.qv1)          # [L, 2*Bd]  q | v1
         kv2 = ops.linear(b, bc.kv2)          # [L2, 2*Bd] k | v2
-        ops.qk_prep(qv1[:, :Bd], Hb, hd, rope="interleaved", table=tabs["bi_dit"] if sh is None else tabs["bi_dit_local"])
+        # the scale goes on q only: direction 1 uses q as queries, direction 2 uses it as keys -- one factor either way
+        ops.qk_prep(qv1[:, :Bd], Hb, hd, rope="interleaved", table=tabs["bi_dit"] if sh is None else tabs["bi_dit_local"],
+                    out_scale=ops.q_scale(hd))
         ops.qk_prep(kv2[:, :Bd], Hb, hd, rope="interleaved", table=tabs["bi_agg"] if sh is None else tabs["bi_agg_local"])
         q_loc, k_loc = qv1[:, :Bd], kv2[:, :Bd]
         if sh is not None:
@@ -280,8 +284,8 @@ class FusionEngine:
             kv2_all = sh.all_gather_rows(kv2, sh.agg_counts)
         else:
             qv1_all, kv2_all = qv1, kv2
-        o1 = ops.attention(q_loc, kv2_all[:, :Bd], kv2_all[:, Bd:], Hb, hd)      # softmax(q k^T) v2
-        o2 = ops.attention(k_loc, qv1_all[:, :Bd], qv1_all[:, Bd:], Hb, hd)      # softmax(k q^T) v1
+        o1 = ops.attention(q_loc, kv2_all[:, :Bd], kv2_all[:, Bd:], Hb, hd, q_prescaled=True)      # softmax(q k^T) v2
+        o2 = ops.attention(k_loc, qv1_all[:, :Bd], qv1_all[:, Bd:], Hb, hd, q_prescaled=True)      # softmax(k q^T) v1
         ops.linear(o1, bc.out1, g1=bc.gamma1, res=x, out_f32=True, out=x)
         ops.linear(o2, bc.out2, g1=bc.gamma2, res=tok, out_f32=True, out=tok)
 

@@ -22,7 +22,7 @@ ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
 SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
-    "fw_cast_f32_bf16", "fw_set_option",
+    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps",
 ]
 
 _lib = None
@@ -49,7 +49,7 @@ def load_library(path: str = LIB_PATH):
         "fw_attention_bf16": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, i32, vp],
         "fw_v_transpose": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_layernorm_mod": [vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp],
-        "fw_qk_prep": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, vp],
+        "fw_qk_prep": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, f32, vp],
         "fw_gemv_f32": [vp, vp, i64, vp, vp, i32, i32, i32, i32, vp],
         "fw_sinusoid": [vp, i32, vp, i32, vp],
         "fw_patchify": [vp, i32, vp, i32, i32, vp, i64, i32, i32, i32, vp],
@@ -57,12 +57,13 @@ def load_library(path: str = LIB_PATH):
         "fw_assemble_tokens": [vp, i64, vp, vp, i32, i32, i32, i32, vp],
         "fw_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
         "fw_set_option": [i32, i32],
+        "fw_debug_attention_timestamps": [vp, i32],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    if lib.fw_abi_version() != 1:
+    if lib.fw_abi_version() != 2:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -195,14 +196,16 @@ class HipOps:
                "fw_layernorm_mod")
         return out
 
-    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None):
-        """In place on x [rows, heads*hd] (may be a column slice of a wider buffer)."""
+    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0):
+        """In place on x [rows, heads*hd] (may be a column slice of a wider buffer).  out_scale: multiplied in before the
+        single bf16 rounding (the engine folds softmax_scale*log2(e) into q: see attention(q_prescaled=True))."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == heads * hd
         tab_rows = 0 if table is None else table.shape[0]
         if table is not None:
             assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1:] == (hd // 2, 2)
         _check(self.lib.fw_qk_prep(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, NORM[norm], _ptr(norm_w),
-                                   _ptr(norm_b), float(eps), ROPE[rope], _ptr(table), tab_rows, self._stream()),
+                                   _ptr(norm_b), float(eps), ROPE[rope], _ptr(table), tab_rows, float(out_scale),
+                                   self._stream()),
                "fw_qk_prep")
         return x
 
@@ -217,8 +220,14 @@ class HipOps:
                                        hd, Lk, self._stream()), "fw_v_transpose")
         return vt, Lk
 
-    def attention(self, q, k, v, heads, hd, batch=1, out=None, accumulate=False, v_prepared=None):
-        """softmax(q k^T / sqrt(hd)) v per (batch, head); q [batch*Lq, heads*hd], k/v [batch*Lk, heads*hd]."""
+    @staticmethod
+    def q_scale(hd):
+        """The factor folded into q by qk_prep(out_scale=...) for attention(q_prescaled=True): softmax scale * log2(e)."""
+        return 1.4426950408889634 / math.sqrt(hd)
+
+    def attention(self, q, k, v, heads, hd, batch=1, out=None, accumulate=False, v_prepared=None, q_prescaled=False):
+        """softmax(q k^T / sqrt(hd)) v per (batch, head); q [batch*Lq, heads*hd], k/v [batch*Lk, heads*hd].
+        q_prescaled: q already carries q_scale(hd) (scores are then used directly in the log2 domain)."""
         assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and q.stride(1) == 1 and k.stride(1) == 1
         Lq = q.shape[0] // batch
         Lk = k.shape[0] // batch
@@ -233,7 +242,8 @@ class HipOps:
         _check(self.lib.fw_attention_bf16(
             q.data_ptr(), q.stride(0), Lq * q.stride(0), k.data_ptr(), k.stride(0), Lk * k.stride(0),
             vt.data_ptr(), vt.shape[-1], out.data_ptr(), out.stride(0), Lq * out.stride(0),
-            batch, heads, hd, Lq, Lk, 1.0 / math.sqrt(hd), int(accumulate), self._stream()), "fw_attention_bf16")
+            batch, heads, hd, Lq, Lk, 1.0 / math.sqrt(hd), (1 if accumulate else 0) | (2 if q_prescaled else 0),
+            self._stream()), "fw_attention_bf16")
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(self.device))
             self._timing["events"].append(ev)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 1
+#define FW_ABI_VERSION 2
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -63,9 +63,15 @@ int fw_abi_version(void);
 #define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 3 = 128-B-row ping-pong with quarter-slab DMA (default), 1 = 5-deep half-slab ring,
                                   2 = four-wave 128x128 wave tile, 0 = first 2-stage staggered kernel (A/B baselines) */
 #define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: schedule variant bits of the selected 256x256 kernel (default 1 = s_setprio around MFMA bursts) */
-#define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: schedule variant bits of the attention kernel */
+#define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 64 (default) = two-segment ping-pong kernels (log2-domain fast path when
+                                  FW_ATTN_Q_PRESCALED, else the generic two-segment kernel); 32+bits / 16+bits / 0 = earlier
+                                  schedules kept as A/B baselines; 66 = timing build (fw_debug_attention_timestamps) */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
+
+/* Measurement hook: shader-clock timestamps [wave 0..7][8] of work-group 0 at KV tile 100, written by the TIMING build of the
+ * ping-pong attention kernel (FW_ATTN_VAR = 66); synchronous copy to host memory. */
+int fw_debug_attention_timestamps(unsigned long long* host_out, int n);
 
 /* Human-readable description of the last negative error on this thread (never NULL). */
 const char* fw_last_error(void);
@@ -96,16 +102,21 @@ int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
  *   Q : [batch][Lq][heads*hd] bf16, row stride ldq, batch stride bsq (elements); same for K (ldk, bsk).
  *   Vt: [batch][heads][hd][Lk_pad] bf16, produced by fw_v_transpose (keys permuted inside each 32-block,
  *       zero padded to Lk_pad = roundup(Lk, 64)).
- *   O : [batch][Lq][heads*hd] bf16 (ldo, bso).  accumulate != 0 -> O += result (cross-attn text+image sum,
- *       DIT21:197-200).
+ *   O : [batch][Lq][heads*hd] bf16 (ldo, bso).
+ *   flags: FW_ATTN_ACCUMULATE -> O += result (cross-attn text+image sum, DIT21:197-200);
+ *          FW_ATTN_Q_PRESCALED -> Q already carries the factor scale*log2(e) (fw_qk_prep out_scale): `scale` is ignored, the
+ *          scores are used in the log2 domain as they come out of the MFMA (saves one multiply-add per score and lets the
+ *          running max be folded into the accumulator input of QK^T) -- the fast ping-pong kernel needs this form.
  * fp32 online softmax, bf16 MFMA 32x32x16 for QK^T and PV.
  */
+#define FW_ATTN_ACCUMULATE  1
+#define FW_ATTN_Q_PRESCALED 2
 int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
                       const uint16_t* K, int64_t ldk, int64_t bsk,
                       const uint16_t* Vt, int64_t Lk_pad,
                       uint16_t* O, int64_t ldo, int64_t bso,
                       int batch, int heads, int head_dim, int Lq, int Lk,
-                      float scale, int accumulate, void* stream);
+                      float scale, int flags, void* stream);
 
 /*
  * V[batch][Lk][heads*hd] (ldv, bsv) -> Vt[batch][heads][hd][Lk_pad] in the key order fw_attention_bf16 expects.
@@ -127,13 +138,15 @@ int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_t* y, int64
 /*
  * In-place q/k post-projection: normalisation + rotary embedding on a [rows][heads*hd] bf16 slice (ldx).
  *   norm_mode: FW_NORM_*; norm_w (and norm_b for LN_HEAD) fp32.
+ *   out_scale: the result is multiplied by out_scale in fp32 before the single bf16 rounding (1.0f = none); the engine
+ *   folds softmax_scale*log2(e) into q here (see FW_ATTN_Q_PRESCALED).
  *   rope_mode: FW_ROPE_*; rope_tab = fp32 [tab_rows][hd/2][2] (cos,sin), row used = row % tab_rows
  *   (DIT21:97-102,170-182 RMSNorm+RoPE3D; VA:55-59 + VR:154-188; IRG:547-551 with the identity rows of
  *    DIT21:105-132 baked into the table).
  */
 int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim,
                int norm_mode, const float* norm_w, const float* norm_b, float eps,
-               int rope_mode, const float* rope_tab, int tab_rows, void* stream);
+               int rope_mode, const float* rope_tab, int tab_rows, float out_scale, void* stream);
 
 /*
  * out[n] = act( sum_k x[k]*W[n,k] + bias[n] ), all fp32, M = 1 (time embeddings:

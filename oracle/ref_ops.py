@@ -102,7 +102,7 @@ class TorchRefOps:
             y = y + shift
         return self._r(y)
 
-    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None):
+    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0):
         rows = x.shape[0]
         v = x.to(torch.float32)
         if norm == "rms_full":
@@ -126,20 +126,24 @@ class TorchRefOps:
             else:
                 raise ValueError(rope)
             v = o.reshape(rows, heads * hd)
-        x.copy_(self._r(v))
+        x.copy_(self._r(v * out_scale))
         return x
 
     def prepare_v(self, v, heads, hd, batch=1):
         return (v, v.shape[0] // batch)
 
-    def attention(self, q, k, v, heads, hd, batch=1, out=None, accumulate=False, v_prepared=None):
+    @staticmethod
+    def q_scale(hd):
+        return 1.4426950408889634 / math.sqrt(hd)
+
+    def attention(self, q, k, v, heads, hd, batch=1, out=None, accumulate=False, v_prepared=None, q_prescaled=False):
         if v_prepared is not None:
             v = v_prepared[0]
         Lq, Lk = q.shape[0] // batch, k.shape[0] // batch
         qh = q.reshape(batch, Lq, heads, hd).transpose(1, 2).to(torch.float32)
         kh = k.reshape(batch, Lk, heads, hd).transpose(1, 2).to(torch.float32)
         vh = v.reshape(batch, Lk, heads, hd).transpose(1, 2).to(torch.float32)
-        s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(hd))
+        s = (qh @ kh.transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else 1.0 / math.sqrt(hd))
         o = torch.softmax(s, dim=-1) @ vh
         o = o.transpose(1, 2).reshape(batch * Lq, heads * hd)
         if accumulate:

@@ -154,15 +154,24 @@ def test_gemv_f32(ops, ref):
 
 
 # --------------------------------------------------------------------------------------------------------- attention
-DEFAULT_ATTN_VAR = 0
+DEFAULT_ATTN_VAR = 64
 
 
-@pytest.fixture(params=[0, 17, 19], ids=["attn_v0", "attn_pp_prio", "attn_pp_prio_defer"])
+@pytest.fixture(params=[0, 18, 34, 64, 65], ids=["attn_v0", "attn_pp4_defer", "attn_pp2", "attn_pp3", "attn_pp3_dmaqk"])
 def attn_variant(ops, request):
-    """Every attention test runs on the first kernel (0) and on the ping-pong kernel (16 + schedule bits)."""
+    """Every attention test runs on the first kernel (0), on the 4- and 2-segment ping-pong kernels, and on the fast
+    log2-domain kernel (64+), which is selected when q carries the softmax scale (q_prescaled=True)."""
     ops.set_option("attn_var", request.param)
     yield request.param
     ops.set_option("attn_var", DEFAULT_ATTN_VAR)
+
+
+def _prescale(ops, variant, q, hd):
+    """variant >= 64: fold softmax_scale*log2(e) into q (what qk_prep's out_scale does), one bf16 rounding."""
+    if variant >= 64:
+        return (q * ops.q_scale(hd)).to(torch.bfloat16).float(), True
+    return q, False
+
 
 ATTN_CASES = [  # heads, hd, batch, Lq, Lk
     (3, 128, 1, 300, 333), (2, 128, 1, 64, 64), (5, 128, 1, 1000, 257), (2, 128, 1, 257, 512),
@@ -173,8 +182,9 @@ ATTN_CASES = [  # heads, hd, batch, Lq, Lk
 @pytest.mark.parametrize("heads,hd,batch,Lq,Lk", ATTN_CASES)
 def test_attention_matches_softmax_reference(attn_variant, ops, ref, heads, hd, batch, Lq, Lk):
     q, k, v = rnd(batch * Lq, heads * hd, seed=1), rnd(batch * Lk, heads * hd, seed=2), rnd(batch * Lk, heads * hd, seed=3)
-    want = ref.attention(q, k, v, heads, hd, batch=batch)
-    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, batch=batch)
+    q, pre = _prescale(ops, attn_variant, q, hd)
+    want = ref.attention(q, k, v, heads, hd, batch=batch, q_prescaled=pre)
+    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, batch=batch, q_prescaled=pre)
     assert rel_l2(got.float(), want) < 4e-3
 
 
@@ -183,28 +193,50 @@ def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref):
     heads, hd, L, Lc = 4, 128, 200, 77
     D = heads * hd
     qkv = rnd(L, 3 * D, seed=4)
+    qkv[:, :D], pre = _prescale(ops, attn_variant, qkv[:, :D].clone(), hd)
     ctx = rnd(Lc, 2 * D, seed=5)
-    want = ref.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], heads, hd)
-    want2 = want + ref.attention(qkv[:, :D], ctx[:, :D], ctx[:, D:], heads, hd)
+    want = ref.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], heads, hd, q_prescaled=pre)
+    want2 = want + ref.attention(qkv[:, :D], ctx[:, :D], ctx[:, D:], heads, hd, q_prescaled=pre)
     g = bf(qkv).cuda()
     c = bf(ctx).cuda()
-    got = ops.attention(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], heads, hd)
+    got = ops.attention(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], heads, hd, q_prescaled=pre)
     assert rel_l2(got.float(), want) < 4e-3
-    ops.attention(g[:, :D], c[:, :D], c[:, D:], heads, hd, out=got, accumulate=True)
+    ops.attention(g[:, :D], c[:, :D], c[:, D:], heads, hd, out=got, accumulate=True, q_prescaled=pre)
     assert rel_l2(got.float(), want2) < 5e-3
 
 
-def test_attention_large_score_spike(attn_variant, ops, ref):
-    """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence."""
+@pytest.mark.parametrize("gain", [3.0, 40.0])
+def test_attention_large_score_spike(attn_variant, ops, ref, gain):
+    """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence (gain 40: the spike is
+    ~2^900 above everything else in the exponent domain -- the probabilities of the stale max overflow to inf and the slow
+    path has to recover), a row whose max is set in tile 0 and never changes, and a row whose scores are all very negative."""
     heads, hd, Lq, Lk = 1, 128, 64, 640
     q, k, v = rnd(Lq, hd, seed=6), rnd(Lk, hd, seed=7), rnd(Lk, hd, seed=8)
-    k[600] = q[5] * 3.0         # row 5's max jumps at tile 9
-    k[10] = q[9] * 4.0          # row 9's max is set in tile 0 and never changes
+    k[600] = q[5] * gain        # row 5's max jumps at tile 9
+    k[10] = q[9] * (gain + 1)   # row 9's max is set in tile 0 and never changes
+    k[3] = -q[20] * 2.0         # row 20 has one strongly negative score in tile 0
     k = k.to(torch.bfloat16).float()
-    want = ref.attention(q, k, v, heads, hd)
-    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd)
-    assert rel_l2(got.float(), want) < 4e-3
+    q, pre = _prescale(ops, attn_variant, q, hd)
+    want = ref.attention(q, k, v, heads, hd, q_prescaled=pre)
+    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, q_prescaled=pre)
     assert torch.isfinite(got.float()).all()
+    assert rel_l2(got.float(), want) < 4e-3
+
+
+def test_attention_all_scores_far_below_zero(attn_variant, ops, ref):
+    """Every score of every row is << 0 (q = -20 k-ish): exp2 of the unshifted scores underflows; the first-tile max must
+    anchor the running max or the row sums vanish."""
+    heads, hd, Lq, Lk = 2, 64, 96, 200
+    base = rnd(1, heads * hd, seed=9).abs() + 0.5
+    q = base.repeat(Lq, 1) * 6.0 + 0.1 * rnd(Lq, heads * hd, seed=10)
+    k = -base.repeat(Lk, 1) * 6.0 + 0.1 * rnd(Lk, heads * hd, seed=11)
+    v = rnd(Lk, heads * hd, seed=12)
+    q, k = q.to(torch.bfloat16).float(), k.to(torch.bfloat16).float()
+    q, pre = _prescale(ops, attn_variant, q, hd)
+    want = ref.attention(q, k, v, heads, hd, q_prescaled=pre)
+    got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, q_prescaled=pre)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got.float(), want) < 4e-3
 
 
 def test_attention_full_length_properties(attn_variant, ops):
@@ -215,14 +247,17 @@ def test_attention_full_length_properties(attn_variant, ops):
     q = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     k = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     v = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    pre = attn_variant >= 64
+    qs = (q.float() * ops.q_scale(hd)).to(torch.bfloat16) if pre else q
+    sc = 0.6931471805599453 if pre else 1.0 / math.sqrt(hd)
     ones = torch.full_like(v, 0.5)
-    o1 = ops.attention(q, k, ones, heads, hd)
+    o1 = ops.attention(qs, k, ones, heads, hd, q_prescaled=pre)
     assert (o1.float() - 0.5).abs().max().item() < 4e-3
-    o = ops.attention(q, k, v, heads, hd)
+    o = ops.attention(qs, k, v, heads, hd, q_prescaled=pre)
     rows = torch.tensor([0, 1, 255, 256, 9999, 16383, 32503, 32759], device="cuda")
     for h in range(heads):
         sl = slice(h * hd, (h + 1) * hd)
-        s = (q[rows][:, sl].float() @ k[:, sl].float().t()) / math.sqrt(hd)
+        s = (qs[rows][:, sl].float() @ k[:, sl].float().t()) * sc
         want = torch.softmax(s, dim=-1) @ v[:, sl].float()
         assert rel_l2(o[rows][:, sl].float(), want) < 6e-3
 
@@ -301,6 +336,26 @@ def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref):
     ops.qk_prep(xg, heads, hd, None, None, None, 1e-6, "interleaved", tab.cuda())
     assert rel_l2(xg.float(), xr) < 4e-3
     assert torch.equal(xg[:5].float().cpu(), x[:5])                                # identity rows bit-exact
+
+
+def test_qk_prep_out_scale(ops, ref):
+    """out_scale is applied in fp32 before the single bf16 rounding (q carries softmax_scale*log2e into attention)."""
+    from fantasy_world_amd import rope
+    heads, hd, f, h, w = 40, 128, 1, 3, 4
+    tab = rope.rope3d_table(hd, f, h, w)
+    x = rnd(f * h * w, heads * hd, seed=13)
+    nw = 1 + 0.1 * torch.randn(heads * hd, generator=torch.Generator().manual_seed(1))
+    xr = x.clone()
+    ref.qk_prep(xr, heads, hd, "rms_full", nw, None, 1e-6, "interleaved", tab, out_scale=ops.q_scale(hd))
+    xg = bf(x).cuda()
+    ops.qk_prep(xg, heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab.cuda(), out_scale=ops.q_scale(hd))
+    assert rel_l2(xg.float(), xr) < 4e-3
+    # and through the generic (block-per-row) kernel: odd head count -> width not a multiple of 64 chunks is still wave path;
+    # force the fallback with a misaligned table pointer
+    tab2 = torch.cat([torch.zeros(1), tab.reshape(-1)]).cuda()[1:].view(tab.shape)
+    xg2 = bf(x).cuda()
+    ops.qk_prep(xg2, heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab2, out_scale=ops.q_scale(hd))
+    assert rel_l2(xg2.float(), xr) < 4e-3
 
 
 def test_qk_prep_rms_no_rope(ops, ref):

@@ -44,7 +44,7 @@ def main():
     rb = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
 
     gvars = [tuple(int(a) for a in v.split(":")) for v in args.gemm_variants.split(",") if v] or [(3, 1)]
-    avars = [int(v) for v in args.attn_variants.split(",") if v] or [0]
+    avars = [int(v) for v in args.attn_variants.split(",") if v] or [64]
     if args.only in ("", "gemm"):
       for (gk, gv) in gvars:
         ops.set_option("gemm_kernel", gk)
@@ -81,9 +81,11 @@ def main():
                                         (12, 96, 1, L, L2, "bicross"), (16, 64, 1, L2, L2, "vggt global"),
                                         (16, 64, 21, L2 // 21, L2 // 21, "vggt frame")]:
             q, k, v = rb(B * Lq, H * hd), rb(B * Lk, H * hd), rb(B * Lk, H * hd)
+            if av >= 64:
+                q = (q.float() * ops.q_scale(hd)).to(torch.bfloat16)     # what qk_prep(out_scale=...) hands the fast kernel
             vp = ops.prepare_v(v, H, hd, B)
             out = torch.empty(B * Lq, H * hd, dtype=torch.bfloat16, device=dev)
-            ms = timeit(lambda: ops.attention(q, k, None, H, hd, batch=B, out=out, v_prepared=vp), args.iters)
+            ms = timeit(lambda: ops.attention(q, k, None, H, hd, batch=B, out=out, v_prepared=vp, q_prescaled=av >= 64), args.iters)
             tf = 4.0 * B * Lq * Lk * H * hd / ms / 1e9
             res.append(dict(kernel="attention", variant=av, tag=tag, H=H, hd=hd, B=B, Lq=Lq, Lk=Lk, ms=ms, tflops=tf, frac=tf / 2500))
             print(f"attn {tag:14s} H={H:3d} hd={hd:3d} B={B:2d} Lq={Lq:6d} Lk={Lk:6d}  {ms:8.3f} ms  {tf:7.1f} TF/s  {tf/25:5.1f}% of peak", flush=True)
@@ -91,7 +93,7 @@ def main():
             gb = 2.0 * v.numel() * 2 / ms / 1e6
             print(f"     v_transpose {tag:14s} {ms:8.3f} ms  {gb:7.1f} GB/s", flush=True)
             del q, k, v, vp, out
-      ops.set_option("attn_var", 0)
+      ops.set_option("attn_var", 64)
     if args.only in ("", "glue"):
         x = torch.randn(L, 5120, device=dev)
         sc = torch.randn(5120, device=dev)
