@@ -9,8 +9,8 @@ Workload: BASELINE.json configs[1] -- Wan2.1-I2V-14B-480P + IRG fusion + VGGT ge
 (latents [1,16,21,60,104], L = 32760 DiT tokens, L2 = 32865 VGGT tokens), random weights of the real architecture
 (40 DiT blocks, 24+24 VGGT blocks, 24 bicross blocks, 25 camera adapters), synthetic inputs.  One step = 2
 joint_forward calls (CFG positive + negative, return_prediction=False) + CFG combine + flow-match Euler update
-(FantasyWorld/fusion/model_wan21.py:289-322).  N > 1: the single sample is sequence-sharded over the ranks
-(fantasy_world_amd/parallel.py), i.e. strong scaling.
+(FantasyWorld/fusion/model_wan21.py:289-322).  N > 1 (fantasy_world_amd/parallel.py): the two CFG forwards go to two rank
+groups, each group sequence-shards its forward (head all-to-all for attention), i.e. strong scaling of one sample.
 
 Prints ONE JSON line on rank 0 (see README / task contract) with `roofline` for the dominant kernel (the hd-128
 self-attention launch, 41% of the forward's FLOPs) and, at N = 1, `cpu_baseline`.
@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 from fantasy_world_amd import config as fwc, synth                      # noqa: E402
 from fantasy_world_amd.engine import FusionEngine                       # noqa: E402
 from fantasy_world_amd.hip_ops import HipOps                            # noqa: E402
-from fantasy_world_amd.parallel import init_from_env                    # noqa: E402
+from fantasy_world_amd.parallel import init_topology                    # noqa: E402
 from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step  # noqa: E402
 
 MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
@@ -98,7 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    shard, rank, world, local = init_from_env()
+    topo = init_topology()
+    shard, rank, world, local = topo.shard, topo.rank, topo.world, topo.local
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = f"cuda:{local}"
@@ -135,13 +136,13 @@ def main():
 
     step_id = 0
     for _ in range(args.warmup):
-        latents, _ = denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond)
+        latents, _ = denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo)
         step_id += 1
     ops.start_kernel_timing("attn_hd128_self", lambda kw: kw["hd"] == 128 and kw["Lk"] >= L)
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        latents, _ = denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond)
+        latents, _ = denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo)
         step_id += 1
     barrier()
     dt = time.time() - t0
@@ -156,9 +157,18 @@ def main():
     step_flops = 2.0 * f_fwd
     value = args.steps / dt
     # dominant kernel: one hd-128 self-attention launch = 4 * Lq_local * L * D FLOP (QK^T + PV)
-    lq = L if shard is None else shard.dit_counts[rank]
-    attn_flops = 4.0 * lq * L * cfg.dim
+    # (sharded: L rows x 40/n heads per rank after the head exchange = the same FLOPs as L/n rows x 40 heads)
+    attn_flops = 4.0 * L * L * cfg.dim / topo.sp_world
     achieved = attn_flops / (attn_ms * 1e-3) if attn_n else 0.0
+    # HBM-side traffic of the dominant kernel: measured with rocprofv3 PMC counters in separate passes (FETCH_SIZE, WRITE_SIZE)
+    # as MI355X_MICROARCH.md prescribes, recorded under profiles/ with provenance; bench.py only reports the stored measurement
+    # (a PMC pass cannot run inside the timed process).  Valid for the unsharded launch shape only.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+            traffic = float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"]) if topo.sp_world == 1 else None
+    except (OSError, KeyError, ValueError):
+        traffic = None
     out = {
         "metric": "denoise-steps/sec (81x480x832 latents, 14B WanDiT + IRG + VGGT branch)",
         "value": value, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,13 +178,15 @@ def main():
                                if args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
                                else f"DEBUG layers={args.layers} {args.frames}f x {args.height} x {args.width}",
                    "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,
-                   "parallelism": "single GPU" if world == 1 else f"sequence-sharded x{world} (K/V all-gather over RCCL)",
+                   "parallelism": topo.describe(),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
-        "roofline": {"bound": "mfma", "kernel": "attention_kernel<128> (DiT self-attention, one launch per block)",
+        "roofline": {"bound": "mfma", "kernel": "attention_pp3_kernel<128> (DiT self-attention, one launch per block)",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
-                     "flops_per_launch": attn_flops, "traffic": None},
+                     "flops_per_launch": attn_flops, "traffic": traffic,
+                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json)",
+                     "algorithmic_bytes_per_launch": 4.0 * L * cfg.dim * 2 / topo.sp_world},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, step_flops)

@@ -202,10 +202,16 @@ class FusionEngine:
         ops.qk_prep(q, H, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
                     out_scale=ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab)
-        if sh is not None:
-            kv = sh.all_gather_rows(qkv[:, D:], sh.dit_counts)   # [L, 2D] (k | v) of every rank
-            k, v = kv[:, :D], kv[:, D:]
-        o = ops.attention(q, k, v, H, hd, q_prescaled=True)
+        if sh is not None and sh.heads_divisible(H):
+            # head exchange: my rows / all heads -> all rows / my heads, attention over the full sequence, and back
+            t = sh.rows_to_heads(qkv, 3, sh.dit_counts)          # [L, 3, (H/n)*hd]
+            o = ops.attention(t[:, 0], t[:, 1], t[:, 2], H // sh.world, hd, q_prescaled=True)
+            o = sh.heads_to_rows(o, sh.dit_counts)               # [L/n, D]
+        else:
+            if sh is not None:
+                kv = sh.all_gather_rows(qkv[:, D:], sh.dit_counts)   # [L, 2D] (k | v) of every rank
+                k, v = kv[:, :D], kv[:, D:]
+            o = ops.attention(q, k, v, H, hd, q_prescaled=True)
         ops.linear(o, blk.o, g1=mod[2], res=x, out_f32=True, out=x)
         # cross-attention: text + image keys share q; outputs are summed (wan_video_dit.py:185-201)
         xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
@@ -248,10 +254,15 @@ class FusionEngine:
                     rope="half2d", table=tabs["vggt"], out_scale=ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="ln_head", norm_w=blk.k_norm[0], norm_b=blk.k_norm[1], eps=cfg.vggt_eps,
                     rope="half2d", table=tabs["vggt"])
-        if not frame_mode and sh is not None:
-            kv = sh.all_gather_rows(qkv[:, C:], sh.agg_counts)
-            k, v = kv[:, :C], kv[:, C:]
-        o = ops.attention(q, k, v, H, hd, batch=batch, q_prescaled=True)
+        if not frame_mode and sh is not None and sh.heads_divisible(H):
+            t = sh.rows_to_heads(qkv, 3, sh.agg_counts)          # global attention: all tokens, my heads
+            o = ops.attention(t[:, 0], t[:, 1], t[:, 2], H // sh.world, hd, batch=1, q_prescaled=True)
+            o = sh.heads_to_rows(o, sh.agg_counts)
+        else:
+            if not frame_mode and sh is not None:
+                kv = sh.all_gather_rows(qkv[:, C:], sh.agg_counts)
+                k, v = kv[:, :C], kv[:, C:]
+            o = ops.attention(q, k, v, H, hd, batch=batch, q_prescaled=True)
         ops.linear(o, blk.proj, g1=blk.ls1, res=tok, out_f32=True, out=tok)
         return e
 

@@ -1,17 +1,28 @@
-"""Sequence-sharded execution of joint_forward across the GPUs of one node (one process per GPU, RCCL over xGMI).
+"""Multi-GPU execution of the denoising step on one node (one process per GPU, RCCL over xGMI).
 
-Why sequence sharding and not the head/column tensor parallelism a NVSwitch design would pick:
-the path is one sample, so the only free axis is inside the forward.  Head/FFN-column TP needs an all-reduce of the
-full [L, 5120] activation after every row-parallel GEMM (3 per DiT block, ~58 GB of all-reduce payload per forward),
-and on MI355X's point-to-point xGMI mesh a ring all-reduce is bound by ONE link (~153 GB/s).  With 288 GB of HBM per
-GPU the 36 GB of bf16 weights are simply replicated, every token-wise op (LayerNorm, all GEMMs, epilogues) runs on
-L/N local rows with no communication, and the only exchange is an ALL-GATHER of the rotated K and V rows (and the
-bicross q/k/v rows) in front of each attention: ~0.67 GB per DiT block instead of ~2 GB-equivalent of all-reduce,
-no partial sums in reduced precision, no cross-GPU RMSNorm statistics (the full 5120-wide q/k RMSNorm stays local
-to a token), and 12 bicross heads need not divide the GPU count.
+Two levels, chosen from what the path offers and what the xGMI mesh (7 point-to-point links x ~153 GB/s per GPU) is good at:
 
-Layout: DiT tokens are split into `world` contiguous row ranges (L = 32760 = 8 * 4095 at 480p); VGGT tokens are
-split by whole frames (frame attention is per frame) -- 21 frames over 8 ranks = 3,3,3,3,3,2,2,2.
+1. CFG parallelism (outer level, 2 groups).  A denoise step is two INDEPENDENT joint_forward calls (positive / negative
+   prompt, FantasyWorld/fusion/model_wan21.py:295-319) followed by a 4 MB combine.  With an even world size the ranks are split
+   into two groups, each group runs one of the two forwards, and the only exchange is one all-gather of noise_pred per step.
+   At 2 GPUs the forward needs no collective at all.
+
+2. Sequence sharding inside a group (world/2 ranks; world ranks when the world size is odd).  The 36 GB of bf16 weights
+   are replicated (288 GB HBM per GPU); LayerNorm, every GEMM and every fused epilogue run on L/n local rows with no
+   communication -- the GEMMs keep M >= 8190 rows at 8 GPUs, which matters because the 256x256-tile kernels quantise badly
+   below that (M = 4095, N = 5120 is 320 tiles on 256 CUs = 2 rounds).  Only attention needs other ranks' tokens:
+     * DiT self-attention and VGGT global attention: head exchange (all-to-all): the rotated q|k|v rows [L/n, 3*H*hd] go out
+       as n column blocks of H/n heads and come back as [L, 3*(H/n)*hd]; attention runs over the FULL sequence for H/n heads;
+       the output returns by the inverse all-to-all.  Per DiT block each GPU sends (n-1)/n of 126 MB + 42 MB instead of
+       receiving (n-1)/n of the 671 MB k|v all-gather (4x fewer bytes), and still nothing is reduced in low precision.
+     * bicross attention (12 heads, not divisible by 8) and any head count that does not divide: all-gather of the rotated
+       rows (q|v1: 151 MB, k|v2: 151 MB per IRG block).
+   Head/FFN-column tensor parallelism (the NVSwitch habit) would instead all-reduce the full [L,5120] activation three times
+   per DiT block (1.76 GB received per GPU per block, partial sums rounded to bf16, cross-GPU statistics for the full-width
+   q/k RMSNorm) -- see DESIGN.md section 6 for the byte table.
+
+Layout: DiT tokens are split into contiguous row ranges (L = 32760 = 4 * 8190), VGGT tokens by whole frames (frame attention
+is per frame; 21 frames over 4 ranks = 6,5,5,5).
 """
 from typing import List
 
@@ -79,6 +90,33 @@ class SequenceShard:
         dist.all_gather_into_tensor(buf.view(self.world * mx, C), pad, group=self.group)
         return torch.cat([buf[r, : counts[r]] for r in range(self.world)], dim=0)
 
+    def heads_divisible(self, heads):
+        return heads % self.world == 0
+
+    def rows_to_heads(self, t, parts, counts):
+        """Head exchange, forward direction.  t: this rank's rows [counts[rank], parts*H*hd] laid out as `parts` blocks of
+        H*hd columns (q|k|v).  Returns [sum(counts), parts, (H/world)*hd]: every rank's rows (rank order = token order) for
+        this rank's H/world heads.  One all_to_all_single with uneven row splits."""
+        rows, width = t.shape
+        assert rows == counts[self.rank] and width % (parts * self.world) == 0, (t.shape, parts, counts)
+        c = width // (parts * self.world)                       # (H/world)*hd
+        send = t.reshape(rows, parts, self.world, c).permute(2, 0, 1, 3).contiguous()       # [world, rows, parts, c]
+        out = torch.empty(sum(counts), parts, c, dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(out.view(sum(counts), parts * c), send.view(self.world * rows, parts * c),
+                               output_split_sizes=list(counts), input_split_sizes=[rows] * self.world, group=self.group)
+        return out
+
+    def heads_to_rows(self, o, counts):
+        """Inverse exchange for the attention output.  o: [sum(counts), (H/world)*hd] (all rows, my heads) ->
+        [counts[rank], H*hd] (my rows, all heads)."""
+        total, c = o.shape
+        assert total == sum(counts), (o.shape, counts)
+        rows = counts[self.rank]
+        recv = torch.empty(self.world * rows, c, dtype=o.dtype, device=o.device)
+        dist.all_to_all_single(recv, o.contiguous(), output_split_sizes=[rows] * self.world,
+                               input_split_sizes=list(counts), group=self.group)
+        return recv.view(self.world, rows, c).permute(1, 0, 2).reshape(rows, self.world * c)
+
     def dit_rows_to_frames(self, ptok, hw):
         """Bridge (model_wan21.py:170-175): patch tokens are produced in the DiT row split but consumed per frame."""
         full = self.all_gather_rows(ptok, self.dit_counts)
@@ -92,19 +130,66 @@ class SequenceShard:
         return rows.view(1, -1, P, C)
 
 
-def init_from_env(backend=None):
-    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  Returns
-    (shard | None, rank, world, local_rank)."""
+class Topology:
+    """Who this process is: world rank, CFG group (0 = positive prompt, 1 = negative) and the sequence shard inside it."""
+
+    def __init__(self, rank=0, world=1, local=0, cfg_groups=1, cfg_rank=0, shard=None):
+        self.rank, self.world, self.local = rank, world, local
+        self.cfg_groups, self.cfg_rank, self.shard = cfg_groups, cfg_rank, shard
+
+    @property
+    def sp_world(self):
+        return 1 if self.shard is None else self.shard.world
+
+    def describe(self):
+        if self.world == 1:
+            return "single GPU"
+        parts = []
+        if self.cfg_groups == 2:
+            parts.append("CFG-parallel x2")
+        if self.sp_world > 1:
+            parts.append(f"sequence-sharded x{self.sp_world} (head all-to-all + K/V all-gather over RCCL)")
+        return " x ".join(parts)
+
+    def gather_cfg(self, out):
+        """[pos, neg] noise predictions from the two CFG groups (one all-gather over the world group per step)."""
+        bufs = [torch.empty_like(out) for _ in range(self.world)]
+        dist.all_gather(bufs, out.contiguous())
+        return bufs[0], bufs[self.world // 2]
+
+
+def make_topology(rank, world, local=0, cfg_parallel=True):
+    """Process groups for `world` ranks: two CFG groups of world/2 ranks when world is even (and cfg_parallel), each
+    sequence-sharded internally; otherwise one sequence-sharded group.  Every rank must call this (new_group is collective)."""
+    if world == 1:
+        return Topology()
+    if cfg_parallel and world % 2 == 0:
+        n = world // 2
+        groups = [dist.new_group(list(range(g * n, (g + 1) * n))) for g in range(2)]
+        cfg_rank, sp_rank = rank // n, rank % n
+        shard = SequenceShard(sp_rank, n, groups[cfg_rank]) if n > 1 else None
+        return Topology(rank, world, local, 2, cfg_rank, shard)
+    return Topology(rank, world, local, 1, 0, SequenceShard(rank, world))
+
+
+def init_topology(backend=None, cfg_parallel=True):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) -> Topology."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
-        return None, 0, 1, local
+        return Topology(local=local)
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return SequenceShard(rank, world), rank, world, local
+    return make_topology(rank, world, local, cfg_parallel)
+
+
+def init_from_env(backend=None):
+    """Back-compat: (shard | None, rank, world, local_rank) with ONE sequence-sharded group (no CFG split)."""
+    topo = init_topology(backend, cfg_parallel=False)
+    return topo.shard, topo.rank, topo.world, topo.local

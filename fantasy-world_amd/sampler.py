@@ -30,10 +30,18 @@ class FlowMatchScheduler:
 
 
 @torch.no_grad()
-def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cfg_scale=5.0, return_prediction=False):
-    """One sampling step = 2 joint_forward calls (CFG) + combine + scheduler update (M21:289-322)."""
+def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cfg_scale=5.0, return_prediction=False,
+                 topo=None):
+    """One sampling step = 2 joint_forward calls (CFG) + combine + scheduler update (M21:289-322).
+    topo (fantasy_world_amd.parallel.Topology) with two CFG groups: this rank runs only its group's forward and the two
+    noise predictions are exchanged with one all-gather; the geometry prediction lives on the positive-prompt group."""
     t = scheduler.timesteps[step_id].reshape(1).to(device=latents.device, dtype=latents.dtype)
-    pos, pred = engine.joint_forward(latents, t, ctx_pos, return_prediction=return_prediction, **cond)
-    neg, _ = engine.joint_forward(latents, t, ctx_neg, **cond)
+    if topo is not None and topo.cfg_groups == 2:
+        mine = ctx_pos if topo.cfg_rank == 0 else ctx_neg
+        out, pred = engine.joint_forward(latents, t, mine, return_prediction=return_prediction and topo.cfg_rank == 0, **cond)
+        pos, neg = topo.gather_cfg(out)
+    else:
+        pos, pred = engine.joint_forward(latents, t, ctx_pos, return_prediction=return_prediction, **cond)
+        neg, _ = engine.joint_forward(latents, t, ctx_neg, **cond)
     noise_pred = neg + cfg_scale * (pos - neg)
     return scheduler.step(noise_pred, step_id, latents), pred
