@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Per-rank compute time of a sequence-sharded forward, measured on ONE GPU: the collectives of SequenceShard are replaced
+by local stand-ins that return tensors of the right shape (own rows tiled), so every kernel runs at exactly the shapes a rank
+of an n-way group sees (L/n rows for GEMMs and norms, L rows x H/n heads for attention).  compute-only scaling bound =
+t(1) / t(n); communication is NOT included (it is on top: see DESIGN.md section 6 for the byte counts)."""
+import argparse, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fantasy_world_amd import config as fwc, synth
+from fantasy_world_amd.engine import FusionEngine
+from fantasy_world_amd.hip_ops import HipOps
+from fantasy_world_amd.parallel import SequenceShard
+
+
+class LocalShard(SequenceShard):
+    def _tile(self, t, counts):
+        total = sum(counts)
+        reps = (total + t.shape[0] - 1) // t.shape[0]
+        return t.repeat(reps, *([1] * (t.dim() - 1)))[:total].contiguous()
+
+    def all_gather_rows(self, t, counts):
+        return self._tile(t.contiguous(), counts)
+
+    def rows_to_heads(self, t, parts, counts):
+        rows, width = t.shape
+        c = width // (parts * self.world)
+        mine = t.reshape(rows, parts, self.world, c)[:, :, self.rank, :].contiguous()
+        return self._tile(mine, counts)
+
+    def heads_to_rows(self, o, counts):
+        rows = counts[self.rank]
+        return o[:rows].repeat(1, self.world).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sp", default="1,2,4,8")
+    ap.add_argument("--iters", type=int, default=2)
+    args = ap.parse_args()
+    dev = "cuda:0"
+    ops = HipOps(dev)
+    cfg = fwc.wan21_14b()
+    spec = synth.weight_spec(cfg)
+    F, H2, W2 = 21, 60, 104
+    ins = synth.make_inputs(cfg, F, H2, W2, seed=1, device=dev, dtype=torch.bfloat16)
+    cond = dict(clip_feature=ins["clip_feature"], y=ins["y"], plucker_fea=ins["plucker_fea"],
+                plucker_context_lens=ins["plucker_context_lens"])
+    t = torch.tensor([500.0], device=dev, dtype=torch.bfloat16)
+    base = None
+    for n in [int(v) for v in args.sp.split(",")]:
+        shard = None if n == 1 else LocalShard(0, n)
+        eng = FusionEngine(cfg, lambda nm: synth.make_param(nm, spec[nm][0], spec[nm][1], device=dev), ops, shard=shard)
+        eng.joint_forward(ins["x"], t, ins["context"], **cond)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(args.iters):
+            eng.joint_forward(ins["x"], t, ins["context"], **cond)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / args.iters
+        base = base or dt
+        print(f"sp={n}: one forward (rank 0 shapes) {dt*1e3:8.1f} ms   compute-only speed-up vs sp=1: {base/dt:5.2f}x   "
+              f"(x{2 if True else 1} CFG groups -> {2*n} GPUs: step = {dt*1e3:.0f} ms + comm)", flush=True)
+        del eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
