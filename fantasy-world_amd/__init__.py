@@ -3,7 +3,7 @@
 The directory name carries a hyphen (it mirrors the reference repo's name); import it as `fantasy_world_amd`
 (the tiny shim package of that name at the repo root redirects here).
 """
-from .config import FWConfig, wan21_14b, plumbing  # noqa: F401
+from .config import FWConfig, wan21_14b, wan22_a14b, plumbing, plumbing22  # noqa: F401
 from .install import install, uninstall  # noqa: F401
 
-__all__ = ["FWConfig", "wan21_14b", "plumbing", "install", "uninstall"]
+__all__ = ["FWConfig", "wan21_14b", "wan22_a14b", "plumbing", "plumbing22", "install", "uninstall"]

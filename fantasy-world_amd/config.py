@@ -44,6 +44,10 @@ class FWConfig:
     adapter_hidden: int = 1024   # min(hidden, context)//2
     adapter_reduced: int = 409   # context_dim // 5
     adapter_max_block: int = 24  # processors exist on DiT blocks 0..24
+    # Wan2.2-Fun-A14B-Control-Camera: camera conditioning through a conv adapter added to the patch embedding
+    # (diffsynth_wan22/models/wan_video_dit.py:842-858 config, :385-396 patchify), no CLIP context, no per-block adapter
+    control_adapter: bool = False
+    control_in_dim: int = 24
 
     @property
     def head_dim(self):
@@ -72,6 +76,18 @@ class FWConfig:
 def wan21_14b() -> FWConfig:
     """BASELINE.json configs[1]/[2]: Wan2.1-I2V-14B-480P + IRG fusion + VGGT branch."""
     return FWConfig()
+
+
+def wan22_a14b() -> FWConfig:
+    """BASELINE.json configs[3]/[4]: one expert (high- or low-noise) of Wan2.2-Fun-A14B-Control-Camera + IRG fusion + VGGT."""
+    return FWConfig(has_image_input=False, camera_adapter=False, control_adapter=True)
+
+
+def plumbing22(num_layers: int = 2, start_index: int = 1, ffn_dim: int = 13824) -> FWConfig:
+    """Reduced-depth Wan2.2 flavour (widths stay: they are hard-coded in the reference)."""
+    n_irg = num_layers - start_index
+    return FWConfig(num_layers=num_layers, start_index=start_index, ffn_dim=ffn_dim, has_image_input=False,
+                    camera_adapter=False, control_adapter=True, cross_attention_list=list(range(n_irg)))
 
 
 def plumbing(num_layers: int = 2, start_index: int = 1, ffn_dim: int = 13824) -> FWConfig:

@@ -463,6 +463,63 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict
     else ((uint16_t*)out)[o] = f32_to_bf16_bits(v);
 }
 
+
+// Wan2.2 control adapter front end (wan_video_camera_controller.py:24-44): PixelUnshuffle(8) followed by Conv2d(k=2, s=2) is a
+// GEMM over 16x16 pixel patches.  in: [C][F][16h][16w]; out P[L][C*256] bf16 with column (c*64 + dy*8 + dx)*4 + ky*2 + kx
+// (= Conv2d weight [N][C*64][2][2] flattened) = in[c][f][(2h+ky)*8 + dy][(2w+kx)*8 + dx].  One thread per (token, c, dy):
+// two 16-element input rows in, 32 contiguous bf16 out.  Runs once per generation (the result is cached by the engine).
+__global__ __launch_bounds__(256) void control_patchify_kernel(const void* __restrict__ in, int dtype, uint16_t* __restrict__ P,
+                                                               int64_t ldp, int C, int F, int Hh, int Ww) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t L = (int64_t)F * Hh * Ww;
+    if (gid >= L * C * 8) return;
+    const int dy = (int)(gid & 7);
+    const int c = (int)((gid >> 3) % C);
+    const int64_t l = gid / (8 * (int64_t)C);
+    const int w = (int)(l % Ww), h = (int)((l / Ww) % Hh), f = (int)(l / ((int64_t)Ww * Hh));
+    const int Hp = 16 * Hh, Wp = 16 * Ww;
+    uint16_t o[32];
+#pragma unroll
+    for (int ky = 0; ky < 2; ++ky) {
+        const int64_t base = (((int64_t)c * F + f) * Hp + (2 * h + ky) * 8 + dy) * Wp + 16 * w;
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+            for (int dx = 0; dx < 8; ++dx) o[dx * 4 + ky * 2 + kx] = f32_to_bf16_bits(load_any(in, base + kx * 8 + dx, dtype));
+    }
+    uint16_t* dst = P + l * ldp + ((int64_t)c * 64 + dy * 8) * 4;
+#pragma unroll
+    for (int j = 0; j < 32; j += 2) *(uint32_t*)(dst + j) = (uint32_t)o[j] | ((uint32_t)o[j + 1] << 16);
+}
+
+// im2col for a 3x3, pad 1, stride 1 convolution on token-major activations (wan_video_camera_controller.py:64-76
+// ResidualBlock): x [F][h][w][C] bf16 -> out [L][C*9], column c*9 + ky*3 + kx (= Conv2d weight [N][C][3][3] flattened)
+// = x[f][hh+ky-1][ww+kx-1][c], zero outside the frame.  One thread per (token, channel pair); once per generation.
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                        int64_t ldo, int C, int F, int Hh, int Ww) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t L = (int64_t)F * Hh * Ww;
+    const int c2 = C >> 1;
+    if (gid >= L * c2) return;
+    const int c = (int)(gid % c2) * 2;
+    const int64_t l = gid / c2;
+    const int w = (int)(l % Ww), h = (int)((l / Ww) % Hh);
+    uint16_t v[18];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hh = h + ky - 1, ww = w + kx - 1;
+            uint32_t pair = 0;
+            if (hh >= 0 && hh < Hh && ww >= 0 && ww < Ww) pair = *(const uint32_t*)(x + (l + (int64_t)(ky - 1) * Ww + (kx - 1)) * ldx + c);
+            v[ky * 3 + kx] = (uint16_t)(pair & 0xffffu);
+            v[9 + ky * 3 + kx] = (uint16_t)(pair >> 16);
+        }
+    uint16_t* dst = out + l * ldo + (int64_t)c * 9;      // c even -> 4-byte aligned
+#pragma unroll
+    for (int j = 0; j < 18; j += 2) *(uint32_t*)(dst + j) = (uint32_t)v[j] | ((uint32_t)v[j + 1] << 16);
+}
+
 __global__ __launch_bounds__(256) void assemble_tokens_kernel(const uint16_t* __restrict__ patch, int64_t ldp,
                                                               const float* __restrict__ special, float* __restrict__ tokens,
                                                               int S, int hw, int n_special, int C) {
@@ -583,5 +640,22 @@ extern "C" int fw_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_
     const int64_t n = (int64_t)rows * (C / 4);
     if (n <= 0) return 0;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_control_patchify(const void* in, int dtype, uint16_t* P, int64_t ldp, int C, int F, int Hh, int Ww, void* stream) {
+    if (C <= 0 || F <= 0 || Hh <= 0 || Ww <= 0 || (ldp % 2) || ldp < (int64_t)C * 256 || (((uintptr_t)P) & 3) ||
+        (dtype != FW_DT_BF16 && dtype != FW_DT_F32)) { fw_set_error("fw_control_patchify: bad args"); return FW_E_BADARG; }
+    const int64_t n = (int64_t)F * Hh * Ww * C * 8;
+    hipLaunchKernelGGL(control_patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, dtype, P, ldp, C, F, Hh, Ww);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_im2col3x3(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int F, int Hh, int Ww, void* stream) {
+    if (C <= 0 || (C % 2) || (ldx % 2) || (ldo % 2) || ldo < (int64_t)C * 9 || (((uintptr_t)x) & 3) || (((uintptr_t)out) & 3)) {
+        fw_set_error("fw_im2col3x3: C and leading dimensions must be even, bases 4-byte aligned"); return FW_E_BADARG; }
+    const int64_t n = (int64_t)F * Hh * Ww * (C / 2);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, C, F, Hh, Ww);
     return (int)hipGetLastError();
 }

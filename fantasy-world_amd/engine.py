@@ -93,6 +93,12 @@ class FusionEngine:
             self.img1 = lin(pd + "img_emb.proj.1.weight", pd + "img_emb.proj.1.bias")
             self.img3 = lin(pd + "img_emb.proj.3.weight", pd + "img_emb.proj.3.bias")
             self.img_ln4 = (ops.to_f32(g(pd + "img_emb.proj.4.weight")), ops.to_f32(g(pd + "img_emb.proj.4.bias")))
+        if cfg.control_adapter:
+            ca = pd + "control_adapter."
+            self.ctl_conv = lin(ca + "conv.weight", ca + "conv.bias")                                   # [D, 24*64*4]
+            self.ctl_res1 = lin(ca + "residual_blocks.0.conv1.weight", ca + "residual_blocks.0.conv1.bias")   # [D, 9*D]
+            self.ctl_res2 = lin(ca + "residual_blocks.0.conv2.weight", ca + "residual_blocks.0.conv2.bias")
+            self._ctl_cache = None
         self.head_mod = ops.to_f32(g(pd + "head.modulation").reshape(2, cfg.dim))
         self.head = lin(pd + "head.head.weight", pd + "head.head.bias")
         self.dit = [self._pack_dit(b, g, lin, lin_cat) for b in range(cfg.num_layers)]
@@ -301,10 +307,26 @@ class FusionEngine:
         ops.linear(o2, bc.out2, g1=bc.gamma2, res=tok, out_f32=True, out=tok)
 
     # ------------------------------------------------------------------------------------------------ forward
+    def _control_features(self, ctl, F, h, w):
+        """Wan2.2 control adapter (wan_video_camera_controller.py:24-44,64-76): PixelUnshuffle(8) -> Conv2d(k2,s2) ->
+        ResidualBlock(conv3x3 -> ReLU -> conv3x3, + skip), as three GEMMs over gathered patches.  fp32 [L, D], added to the
+        patch embedding (wan_video_dit.py:390-396).  The input is constant over the whole generation (and identical for the
+        positive and negative pass), the reference recomputes it in every call (31 TFLOP at 480p); here it is cached on the
+        identity of the tensor."""
+        ops = self.ops
+        key = (ctl.data_ptr(), tuple(ctl.shape), ctl._version, str(ctl.device))
+        if self._ctl_cache is not None and self._ctl_cache[0] == key:
+            return self._ctl_cache[1]
+        c0 = ops.linear(ops.control_patchify(ctl), self.ctl_conv, out_f32=True)                     # conv k2 s2
+        t1 = ops.linear(ops.im2col3x3(ops.cast_act(c0), F, h, w), self.ctl_res1, act="relu")        # conv1 + ReLU
+        out = ops.linear(ops.im2col3x3(t1, F, h, w), self.ctl_res2, res=c0, out_f32=True)           # conv2 + skip
+        self._ctl_cache = (key, out)
+        return out
+
     @torch.no_grad()
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
                       plucker_context_lens=None, uncond=False, return_prediction=False, camera_token=None,
-                      collect=None):
+                      control_camera_latents_input=None, collect=None):
         """Returns (noise_pred [1,16,F,H,W] in x.dtype, output_list or None).
 
         output_list (only when return_prediction): dict layer -> fp32 [1, S, P, 2*C] for the layers the geometry
@@ -342,7 +364,12 @@ class FusionEngine:
             ctx_img = ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
 
         # ---- A3: patchify (Conv3d k=s=(1,2,2) as GEMM) ---------------------------------------------------------
-        patches = ops.patchify(x, y if cfg.has_image_input else None, self.kpatch)            # [L, 192]
+        # Wan2.1 concatenates y when the DiT has image input (model_wan21.py:125-126), Wan2.2 whenever y is given (model_wan22.py:252-253)
+        use_y = y is not None and (cfg.has_image_input or cfg.control_adapter)
+        patches = ops.patchify(x, y if use_y else None, self.kpatch)                           # [L, 192] (x | y channels)
+        ycam = None
+        if cfg.control_adapter and control_camera_latents_input is not None:
+            ycam = self._control_features(control_camera_latents_input, F, h, w)               # fp32 [L, D]
         plucker = None
         if plucker_fea is not None and cfg.camera_adapter:
             if not self._plucker_all_zero(plucker_fea):                                        # camera_control.py:111
@@ -350,7 +377,8 @@ class FusionEngine:
         if sh is not None:
             patches = sh.take_dit_rows(patches)
             plucker = None if plucker is None else sh.take_dit_rows(plucker)
-        xs = ops.linear(patches, self.patch, out_f32=True)                                    # fp32 residual stream
+            ycam = None if ycam is None else sh.take_dit_rows(ycam)
+        xs = ops.linear(patches, self.patch, res=ycam, out_f32=True)                          # fp32 residual stream
 
         # ---- PCB: DiT blocks [0, start_index) ------------------------------------------------------------------
         for b in range(cfg.start_index):

@@ -22,7 +22,7 @@ ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
 SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
-    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps",
+    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_control_patchify", "fw_im2col3x3",
 ]
 
 _lib = None
@@ -58,6 +58,8 @@ def load_library(path: str = LIB_PATH):
         "fw_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
         "fw_set_option": [i32, i32],
         "fw_debug_attention_timestamps": [vp, i32],
+        "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
+        "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -288,6 +290,28 @@ class HipOps:
         out = torch.empty(S * (n_special + hw), C, dtype=torch.float32, device=self.device)
         _check(self.lib.fw_assemble_tokens(patch.data_ptr(), patch.stride(0), special.data_ptr(), out.data_ptr(),
                                            S, hw, n_special, C, self._stream()), "fw_assemble_tokens")
+        return out
+
+    def control_patchify(self, ctl):
+        """ctl [1, C, F, 16h, 16w] (bf16/f32) -> bf16 [L, C*256]: PixelUnshuffle(8) + k2s2 patch gather of the Wan2.2 control adapter."""
+        ctl = ctl.contiguous()
+        if ctl.dtype not in (torch.bfloat16, torch.float32):
+            ctl = ctl.float()
+        _, C, F, Hp, Wp = ctl.shape
+        assert Hp % 16 == 0 and Wp % 16 == 0, ctl.shape
+        h, w = Hp // 16, Wp // 16
+        out = torch.empty(F * h * w, C * 256, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_control_patchify(ctl.data_ptr(), _dt(ctl), out.data_ptr(), out.stride(0), C, F, h, w, self._stream()),
+               "fw_control_patchify")
+        return out
+
+    def im2col3x3(self, x, F, h, w):
+        """x bf16 [F*h*w, C] token-major -> bf16 [L, 9*C] (3x3, pad 1), column c*9 + ky*3 + kx."""
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[0] == F * h * w
+        C = x.shape[1]
+        out = torch.empty(x.shape[0], 9 * C, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_im2col3x3(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), C, F, h, w, self._stream()),
+               "fw_im2col3x3")
         return out
 
     def cast_act(self, x):

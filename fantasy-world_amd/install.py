@@ -33,8 +33,13 @@ def config_from_model(model) -> FWConfig:
         has_image_input=dit.has_image_input, start_index=model.start_index,
         cross_attention_list=list(model.cross_attention_list), bicross_dim=model.bicross_dim,
         bicross_heads=model.bicross_num_heads, vggt_dim=model.vggt.embed_dim,
-        camera_adapter=bool(getattr(model, "camera_control", False)),
+        # Wan2.1: per-block adapter processors installed by CameraConditionModel (model_wan21.py:55-60);
+        # Wan2.2: camera enters through dit.control_adapter inside patchify (model_wan22.py:254, wan_video_dit.py:385-396)
+        camera_adapter=bool(getattr(model, "camera_control", False)) and hasattr(model, "camera_condition"),
+        control_adapter=getattr(dit, "control_adapter", None) is not None,
     )
+    if cfg.control_adapter:
+        cfg.control_in_dim = dit.control_adapter.conv.in_channels // 64
     return cfg
 
 
@@ -50,11 +55,12 @@ def install(model, ops=None, device=None):
 
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
                       camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,
-                      return_prediction=False, **kwargs):
+                      return_prediction=False, control_camera_latents_input=None, **kwargs):
         out, outputs = engine.joint_forward(x, timestep, context, clip_feature=clip_feature, y=y,
                                             plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
                                             uncond=uncond, return_prediction=return_prediction,
-                                            camera_token=camera_token)
+                                            camera_token=camera_token,
+                                            control_camera_latents_input=control_camera_latents_input)
         if not return_prediction:
             return out, None
         n = cfg.n_irg
@@ -65,8 +71,15 @@ def install(model, ops=None, device=None):
         prediction = self.vggt._head_predction(patch_token, self.vggt.aggregator.patch_start_idx, output_list)
         return out, prediction
 
+    def joint_forward22(self, x, timestep, context, y=None, use_gradient_checkpointing=True, camera_token=None,
+                        control_camera_latents_input=None, uncond=False, return_prediction=False, **kwargs):
+        """Wan2.2 signature (FantasyWorld/fusion/model_wan22.py:231-242)."""
+        return joint_forward(self, x, timestep, context, y=y, camera_token=camera_token, uncond=uncond,
+                             return_prediction=return_prediction,
+                             control_camera_latents_input=control_camera_latents_input)
+
     model._fw_reference_joint_forward = model.joint_forward
-    model.joint_forward = types.MethodType(joint_forward, model)
+    model.joint_forward = types.MethodType(joint_forward22 if cfg.control_adapter else joint_forward, model)
     model._fw_engine = engine
     return engine
 

@@ -93,6 +93,14 @@ def weight_spec(cfg: FWConfig) -> "OrderedDict[str, tuple]":
         _lin(spec, pd + "img_emb.proj.3", d, cfg.clip_dim)
         spec[pd + "img_emb.proj.4.weight"] = ((d,), ("ones_normal", 0.1))
         spec[pd + "img_emb.proj.4.bias"] = ((d,), ("normal", 0.05))
+    if cfg.control_adapter:
+        ca = pd + "control_adapter."
+        kin = cfg.control_in_dim * 64
+        spec[ca + "conv.weight"] = ((d, kin, 2, 2), ("normal", 1.0 / math.sqrt(kin * 4)))
+        spec[ca + "conv.bias"] = ((d,), ("normal", 0.02))
+        for n in ("conv1", "conv2"):
+            spec[ca + f"residual_blocks.0.{n}.weight"] = ((d, d, 3, 3), ("normal", 1.0 / math.sqrt(d * 9)))
+            spec[ca + f"residual_blocks.0.{n}.bias"] = ((d,), ("normal", 0.02))
     c = cfg.vggt_dim
     spec["vggt.projection_head.weight"] = ((c, d, 1, 1, 1), ("normal", 1.0 / math.sqrt(d)))
     spec["vggt.projection_head.bias"] = ((c,), ("normal", 0.02))
@@ -167,6 +175,8 @@ def make_inputs(cfg: FWConfig, f: int, h2: int, w2: int, seed=1, device="cpu", d
         context_neg=r(1, text_len, cfg.text_dim),
         clip_feature=r(1, cfg.clip_tokens, cfg.clip_dim) if cfg.has_image_input else None,
         plucker_fea=r(1, L, cfg.plucker_dim) if cfg.camera_adapter else None,
+        # Wan2.2: Pluecker map folded to 24 channels at pixel resolution (inference_wan22.py:204-218): [1, 24, f, 8*h2, 8*w2]
+        control_camera_latents_input=r(1, cfg.control_in_dim, f, 8 * h2, 8 * w2) if cfg.control_adapter else None,
         timestep=torch.tensor([timestep], dtype=torch.float32),
     )
     lens = torch.ones(f, dtype=torch.long)

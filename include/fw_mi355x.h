@@ -189,6 +189,19 @@ int fw_assemble_tokens(const uint16_t* patch, int64_t ldp, const float* special,
  */
 int fw_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C, void* stream);
 
+/*
+ * Wan2.2 control adapter (FantasyWorld/diffsynth_wan22/models/wan_video_camera_controller.py:8-44, called from
+ * WanModel.patchify, diffsynth_wan22/models/wan_video_dit.py:390-396): PixelUnshuffle(8) + Conv2d(k=2,s=2) as a GEMM over
+ * 16x16 pixel patches.  in [C][F][16*Hh][16*Ww] (bf16 or f32) -> P[L][ldp] bf16, column (c*64 + dy*8 + dx)*4 + ky*2 + kx.
+ */
+int fw_control_patchify(const void* in, int dtype, uint16_t* P, int64_t ldp, int C, int F, int Hh, int Ww, void* stream);
+
+/*
+ * im2col of a 3x3 / pad 1 / stride 1 Conv2d on token-major activations (ResidualBlock,
+ * wan_video_camera_controller.py:64-76): x [F*Hh*Ww][C] bf16 (ldx) -> out [L][9*C] (ldo), column c*9 + ky*3 + kx.
+ */
+int fw_im2col3x3(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int F, int Hh, int Ww, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

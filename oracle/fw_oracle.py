@@ -229,8 +229,19 @@ def bicross(x1, x2, freqs_dit, freqs_agg, W, p, cfg):
 # joint_forward (FantasyWorld/fusion/model_wan21.py:104-224)
 # ---------------------------------------------------------------------------------------------------------------
 @torch.no_grad()
+def control_adapter(ctl, W, pre):
+    # FantasyWorld/diffsynth_wan22/models/wan_video_camera_controller.py:24-44 (SimpleAdapter.forward), :64-76 (ResidualBlock)
+    bs, c, f, h, w = ctl.shape
+    u = F.pixel_unshuffle(ctl.permute(0, 2, 1, 3, 4).reshape(bs * f, c, h, w), 8)
+    xc = F.conv2d(u, W[pre + "conv.weight"], W[pre + "conv.bias"], stride=2)
+    r = pre + "residual_blocks.0."
+    out = F.conv2d(F.relu(F.conv2d(xc, W[r + "conv1.weight"], W[r + "conv1.bias"], padding=1)),
+                   W[r + "conv2.weight"], W[r + "conv2.bias"], padding=1) + xc
+    return out.view(bs, f, out.size(1), out.size(2), out.size(3)).permute(0, 2, 1, 3, 4)      # [b, D, f, h/16, w/16]
+
+
 def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
-                  plucker_context_lens=None, uncond=False, collect=None):
+                  plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None):
     """W: name -> fp32 tensor (reference parameter names). Returns noise_pred [1,16,F,H,W] (fp32).
     The geometry heads (return_prediction) are not part of the oracle: they stay the reference's modules."""
     pd = "pipe.dit."
@@ -240,6 +251,8 @@ def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluck
                W, pd + "time_embedding.2")
     t_mod = linear(F.silu(t), W, pd + "time_projection.1").unflatten(1, (6, cfg.dim))
     ctx = linear(F.gelu(linear(context, W, pd + "text_embedding.0"), approximate="tanh"), W, pd + "text_embedding.2")
+    if cfg.control_adapter and y is not None:
+        x = torch.cat([x, y], dim=1)                       # model_wan22.py:252-253 (require_vae_embedding)
     if cfg.has_image_input:
         x = torch.cat([x, y], dim=1)
         ie = pd + "img_emb.proj."
@@ -249,6 +262,9 @@ def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluck
         ctx = torch.cat([c, ctx], dim=1)
     # patchify (wan_video_dit.py:424-435)
     x = F.conv3d(x, W[pd + "patch_embedding.weight"], W[pd + "patch_embedding.bias"], stride=(1, 2, 2))
+    if cfg.control_adapter and control_camera_latents_input is not None:
+        # diffsynth_wan22/models/wan_video_dit.py:390-396 (patchify: x + control_adapter(control), batch 1)
+        x = x + control_adapter(control_camera_latents_input, W, pd + "control_adapter.")
     _, _, f, h, w = x.shape
     x = x.flatten(2).transpose(1, 2).contiguous()          # b (f h w) c
     hd = cfg.dim // cfg.num_heads

@@ -23,6 +23,8 @@ CASES = {
     # name: (cfg kwargs, (f, h2, w2), timestep, text_len, uncond)
     "wan21_l2_f3_8x8": (dict(num_layers=2, start_index=1), (3, 8, 8), 500.0, 512, False),
     "wan21_l3_f2_12x8": (dict(num_layers=3, start_index=1), (2, 12, 8), 937.5, 512, False),
+    # Wan2.2-Fun-A14B-Control-Camera flavour (model_wan22.py): control adapter in patchify, text-only context, no per-block adapter
+    "wan22_l2_f2_8x12": (dict(num_layers=2, start_index=1), (2, 8, 12), 968.75, 512, False),
 }
 
 
@@ -31,7 +33,7 @@ def rel(a, b):
 
 
 def run_reference(cfg, W, ins, uncond=False):
-    model = ref_harness.build_reference_wan21(cfg, weights=W)
+    model = (ref_harness.build_reference_wan22 if cfg.control_adapter else ref_harness.build_reference_wan21)(cfg, weights=W)
     cap = {}
 
     def hook_pcb(m, a, out):
@@ -44,10 +46,16 @@ def run_reference(cfg, W, ins, uncond=False):
     model.pipe.dit.blocks[cfg.start_index - 1].register_forward_hook(hook_pcb)
     model.IRGBlock[len(cfg.cross_attention_list) - 1].register_forward_hook(hook_irg)
     with torch.no_grad():
-        out, pred = model.joint_forward(
-            ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"],
-            y=ins["y"], use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
-            plucker_context_lens=ins["plucker_context_lens"], uncond=uncond, return_prediction=False)
+        if cfg.control_adapter:      # model_wan22.py:231-242 signature
+            out, pred = model.joint_forward(
+                ins["x"], timestep=ins["timestep"], context=ins["context"], y=ins["y"], use_gradient_checkpointing=False,
+                camera_token=None, control_camera_latents_input=ins["control_camera_latents_input"], uncond=uncond,
+                return_prediction=False)
+        else:
+            out, pred = model.joint_forward(
+                ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"],
+                y=ins["y"], use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+                plucker_context_lens=ins["plucker_context_lens"], uncond=uncond, return_prediction=False)
     assert pred is None
     cap["noise_pred"] = out.detach().clone()
     return cap, model
@@ -56,8 +64,11 @@ def run_reference(cfg, W, ins, uncond=False):
 def main():
     torch.manual_seed(0)
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    only = sys.argv[1:]
     for name, (ckw, (f, h2, w2), ts, tl, uncond) in CASES.items():
-        cfg = fwc.plumbing(**ckw)
+        if only and name not in only:
+            continue
+        cfg = fwc.plumbing22(**ckw) if name.startswith("wan22") else fwc.plumbing(**ckw)
         t0 = time.time()
         W = synth.make_weights(cfg)
         ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=ts, text_len=tl)
@@ -73,7 +84,8 @@ def main():
         col = {}
         t0 = time.time()
         orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
-                                      ins["plucker_fea"], ins["plucker_context_lens"], uncond=uncond, collect=col)
+                                      ins["plucker_fea"], ins["plucker_context_lens"], uncond=uncond, collect=col,
+                                      control_camera_latents_input=ins.get("control_camera_latents_input"))
         print(f"[{name}] oracle forward {time.time()-t0:.1f}s")
         col["noise_pred"] = orc
         for k in ("x_after_pcb", "x_final", "tokens_final", "noise_pred"):
@@ -81,7 +93,7 @@ def main():
         # a second timestep draw through the negative-prompt context (the CFG pair of one denoise step)
         golden = {k: v.to(torch.float32).contiguous() for k, v in ref.items()}
         golden["meta"] = dict(cfg=ckw, grid=(f, h2, w2), timestep=ts, text_len=tl, uncond=uncond, seed_weights=0,
-                              seed_inputs=1, torch=torch.__version__)
+                              seed_inputs=1, torch=torch.__version__, flavour="wan22" if cfg.control_adapter else "wan21")
         path = os.path.join(ROOT, "tests", "golden", name + ".pt")
         torch.save(golden, path)
         print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")

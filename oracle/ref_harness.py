@@ -182,6 +182,66 @@ def build_reference_wan21(cfg, weights=None):
     return model
 
 
+def build_reference_wan22(cfg, weights=None):
+    """Build the reference FantasyWorldFusionModel, Wan2.2-Fun-A14B-Control-Camera flavour (one expert), for `cfg`.
+
+    Mirrors FantasyWorld/fusion/model_wan22.py:122-229 without checkpoints, LoRA or "cuda": diffsynth_wan22 WanModel with the
+    control adapter (config of diffsynth_wan22/models/wan_video_dit.py:842-858), VGGT, IRG assembly loop.
+    """
+    install_stubs()
+    from FantasyWorld.fusion.model_wan22 import FantasyWorldFusionModel
+    from FantasyWorld.fusion.layer.block import IRGBlock
+    from FantasyWorld.diffsynth_wan22.models.wan_video_dit import WanModel, precompute_freqs_cis_3d
+    from FantasyWorld.vggt.models.vggt import VGGT
+
+    torch.manual_seed(0)
+    model = FantasyWorldFusionModel.__new__(FantasyWorldFusionModel)
+    nn.Module.__init__(model)
+    with torch.device("meta") if weights is not None else _nullctx():
+        dit = WanModel(dim=cfg.dim, in_dim=cfg.in_dim, ffn_dim=cfg.ffn_dim, out_dim=cfg.out_dim,
+                       text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, eps=cfg.eps, patch_size=(1, 2, 2),
+                       num_heads=cfg.num_heads, num_layers=cfg.num_layers, has_image_input=False,
+                       add_control_adapter=True, in_dim_control_adapter=cfg.control_in_dim,
+                       require_clip_embedding=False)
+        vggt = VGGT(enable_camera=True, enable_depth=True, enable_point=True, enable_track=False,
+                    DPT_patch_size=16)
+    if weights is not None:
+        dit.freqs = precompute_freqs_cis_3d(cfg.dim // cfg.num_heads)
+        vggt.aggregator.freqs = torch.zeros(1)
+    model.pipe = _FakePipe(dit, None)
+    model.vggt = vggt
+    n_irg = cfg.num_layers - cfg.start_index
+    vggt.aggregator.frame_blocks = nn.ModuleList(list(vggt.aggregator.frame_blocks)[:n_irg])
+    vggt.aggregator.global_blocks = nn.ModuleList(list(vggt.aggregator.global_blocks)[:n_irg])
+    model.camera_control = True
+    model.start_index = cfg.start_index
+    model.use_gradient_checkpointing = False
+    model.use_gradient_checkpointing_offload = False
+    model.cross_attention_list = list(cfg.cross_attention_list)
+    model.device = "cpu"
+    model.bicross_dim = cfg.bicross_dim
+    model.bicross_num_heads = cfg.bicross_heads
+    model.freqs_bicross = precompute_freqs_cis_3d(cfg.bicross_dim // cfg.bicross_heads)
+    irg_blocks = nn.ModuleList()
+    for idx in model.cross_attention_list:
+        src_dit_blk = dit.blocks[idx + model.start_index]
+        src_agg_blk = vggt.aggregator.global_blocks[idx]
+        dit_blk_copy = copy.deepcopy(src_dit_blk)
+        agg_blk_copy = copy.deepcopy(src_agg_blk)
+        dit.blocks[idx + model.start_index] = nn.Identity()
+        vggt.aggregator.global_blocks[idx] = nn.Identity()
+        with torch.device("meta") if weights is not None else _nullctx():
+            irg_blocks.append(IRGBlock(x_dit_block=dit_blk_copy, x_agg_block=agg_blk_copy,
+                                       m1_dim=dit.dim, m2_dim=vggt.embed_dim, hidden_size=model.bicross_dim,
+                                       num_heads=model.bicross_num_heads, drop_path=None))
+    model.IRGBlock = irg_blocks
+    model.use_info = "plucker"
+    if weights is not None:
+        load_named_weights(model, weights)
+    model.eval()
+    return model
+
+
 class _nullctx:
     def __enter__(self):
         return self

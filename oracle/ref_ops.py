@@ -182,5 +182,18 @@ class TorchRefOps:
         sp = torch.stack([special[0 if s == 0 else 1] for s in range(S)], dim=0)
         return torch.cat([sp, pt], dim=1).reshape(S * (n_special + hw), C).contiguous()
 
+    def control_patchify(self, ctl):
+        _, C, F_, Hp, Wp = ctl.shape
+        h, w = Hp // 16, Wp // 16
+        u = F.pixel_unshuffle(ctl[0].to(torch.float32).permute(1, 0, 2, 3), 8)       # [F, C*64, 2h, 2w]
+        p = u.reshape(F_, C * 64, h, 2, w, 2).permute(0, 2, 4, 1, 3, 5).reshape(F_ * h * w, C * 256)
+        return self._r(p)
+
+    def im2col3x3(self, x, F_, h, w):
+        C = x.shape[1]
+        img = x.to(torch.float32).view(F_, h, w, C).permute(0, 3, 1, 2)              # [F, C, h, w]
+        cols = F.unfold(img, kernel_size=3, padding=1)                               # [F, C*9, h*w], row c*9 + ky*3 + kx
+        return self._r(cols.transpose(1, 2).reshape(F_ * h * w, C * 9))
+
     def cast_act(self, x):
         return self._r(x.clone())

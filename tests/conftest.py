@@ -32,7 +32,7 @@ class Case:
         self.name = name
         self.golden = load_golden(name)
         meta = self.golden["meta"]
-        self.cfg = fwc.plumbing(**meta["cfg"])
+        self.cfg = (fwc.plumbing22 if meta.get("flavour") == "wan22" else fwc.plumbing)(**meta["cfg"])
         f, h2, w2 = meta["grid"]
         self.grid = (f, h2, w2)
         self.uncond = meta["uncond"]
@@ -49,3 +49,20 @@ def case_l2():
 @pytest.fixture(scope="session")
 def case_l3():
     return Case("wan21_l3_f2_12x8")
+
+
+@pytest.fixture(scope="session")
+def case_w22():
+    """Wan2.2-Fun-A14B-Control-Camera flavour: control adapter in patchify, text-only context (model_wan22.py)."""
+    return Case("wan22_l2_f2_8x12")
+
+
+def forward_kwargs(case, dev=None):
+    """joint_forward keyword arguments of a case (both flavours), optionally moved to a device."""
+    ins = case.inputs
+    mv = (lambda v: v.to(dev) if torch.is_tensor(v) and dev is not None else v)
+    kw = dict(clip_feature=mv(ins["clip_feature"]), y=mv(ins["y"]), plucker_fea=mv(ins["plucker_fea"]),
+              plucker_context_lens=mv(ins["plucker_context_lens"]), uncond=case.uncond)
+    if ins.get("control_camera_latents_input") is not None:
+        kw["control_camera_latents_input"] = mv(ins["control_camera_latents_input"])
+    return kw

@@ -4,7 +4,7 @@ the oracle and with the reference goldens.  The HIP op set is covered by the -m 
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import rel_l2, forward_kwargs
 from fantasy_world_amd.engine import FusionEngine
 from oracle.ref_ops import TorchRefOps
 
@@ -13,15 +13,13 @@ def _run(case, emulate_bf16):
     eng = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps(emulate_bf16=emulate_bf16))
     ins = case.inputs
     col = {}
-    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"],
-                                  y=ins["y"], plucker_fea=ins["plucker_fea"],
-                                  plucker_context_lens=ins["plucker_context_lens"], uncond=case.uncond, collect=col)
+    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], collect=col, **forward_kwargs(case))
     assert pred is None
     col["noise_pred"] = out
     return col
 
 
-@pytest.mark.parametrize("case_name", ["case_l2", "case_l3"])
+@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22"])
 def test_engine_fp32_matches_golden(case_name, request):
     case = request.getfixturevalue(case_name)
     col = _run(case, emulate_bf16=False)
@@ -49,3 +47,23 @@ def test_all_zero_plucker_skips_adapter(case_l2):
     b, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
                              plucker_fea=None, plucker_context_lens=None)
     assert torch.equal(a, b)
+
+
+def test_wan22_control_features_are_cached_per_tensor(case_w22):
+    """The control adapter output depends only on control_camera_latents_input: computed once, reused for the negative pass
+    and the following steps, recomputed when the tensor changes (in place or a new one)."""
+    case = case_w22
+    eng = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps())
+    ins = case.inputs
+    kw = forward_kwargs(case)
+    a, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+    cached = eng._ctl_cache[1]
+    b, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context_neg"], **kw)
+    assert eng._ctl_cache[1] is cached
+    kw2 = dict(kw, control_camera_latents_input=kw["control_camera_latents_input"] * 2.0)
+    c, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw2)
+    assert eng._ctl_cache[1] is not cached and not torch.equal(a, c)
+    kw["control_camera_latents_input"].mul_(2.0)                      # in-place edit bumps the version counter
+    d, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+    assert torch.equal(c, d)
+    kw["control_camera_latents_input"].mul_(0.5)

@@ -370,6 +370,30 @@ def test_qk_prep_rms_no_rope(ops, ref):
 
 
 # --------------------------------------------------------------------------------------------------------- layout glue
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_control_patchify_is_an_exact_gather(ops, ref, dtype):
+    """Wan2.2 control adapter front end (PixelUnshuffle(8) + k2s2 patches): pure data movement, bit exact."""
+    C, F_, h, w = 24, 2, 3, 5
+    ctl = rnd(1, C, F_, 16 * h, 16 * w, seed=41)
+    want = ref.control_patchify(ctl)
+    got = ops.control_patchify(ctl.to(dtype).cuda())
+    assert got.shape == (F_ * h * w, C * 256) and torch.equal(got.float().cpu(), want)
+
+
+def test_im2col3x3_is_an_exact_gather(ops, ref):
+    """3x3 / pad 1 im2col on token-major activations (ResidualBlock convs of the control adapter), zero borders, bit exact."""
+    F_, h, w, C = 2, 4, 6, 64
+    x = rnd(F_ * h * w, C, seed=42)
+    want = ref.im2col3x3(x, F_, h, w)
+    got = ops.im2col3x3(bf(x).cuda(), F_, h, w)
+    assert torch.equal(got.float().cpu(), want)
+    # and it is the convolution: im2col @ W^T == conv2d
+    wt = rnd(8, C, 3, 3, seed=43, scale=0.1)
+    conv = torch.nn.functional.conv2d(x.view(F_, h, w, C).permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1).reshape(-1, 8)
+    assert rel_l2(got.float().cpu() @ wt.reshape(8, -1).t(), conv) < 1e-5
+
+
+
 def test_sinusoid_bf16_timestep(ops, ref):
     """The sampler hands joint_forward a bf16 timestep (M21:292-293): 999.x -> 1000."""
     for t in (torch.tensor([937.5]), torch.tensor([999.3]).to(torch.bfloat16), torch.tensor([0.0])):

@@ -33,3 +33,26 @@ def test_install_rebinds_joint_forward_on_reference_model(case_l2):
     with torch.no_grad():
         again, _ = model.joint_forward(ins["x"], **kw)
     assert torch.equal(again, want)
+
+
+def test_install_on_reference_wan22_model(case_w22):
+    """Same boundary on the Wan2.2 flavour: the M22 signature (control_camera_latents_input, no clip_feature / plucker_fea,
+    FantasyWorld/fusion/model_wan22.py:231-242) is kept; the engine reads the control adapter off pipe.dit."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install, uninstall
+    case = case_w22
+    model = ref_harness.build_reference_wan22(case.cfg, weights=case.weights)
+    ins = case.inputs
+    kw = dict(timestep=ins["timestep"], context=ins["context"], y=ins["y"], use_gradient_checkpointing=False,
+              camera_token=None, control_camera_latents_input=ins["control_camera_latents_input"], uncond=False,
+              return_prediction=False)
+    with torch.no_grad():
+        want, _ = model.joint_forward(ins["x"], **kw)
+    eng = install(model, ops=TorchRefOps())
+    assert eng.cfg.control_adapter and not eng.cfg.has_image_input and not eng.cfg.camera_adapter
+    got, p1 = model.joint_forward(ins["x"], **kw)           # same call site, same kwargs as inference_wan22.py:243-253
+    assert p1 is None and got.shape == want.shape and got.dtype == want.dtype
+    assert rel_l2(got, want) < 2e-5
+    assert rel_l2(got, case.golden["noise_pred"]) < 2e-5
+    uninstall(model)

@@ -9,7 +9,7 @@ against the fp32 reference; the <= 1e-3 north-star bound is enforced per kernel 
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import rel_l2, forward_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -24,16 +24,16 @@ def _run_hip(case, **over):
     ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
     ins.update(over)
     col = {}
-    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"],
-                                  y=ins["y"], plucker_fea=ins["plucker_fea"],
-                                  plucker_context_lens=ins["plucker_context_lens"], uncond=case.uncond, collect=col)
+    kw = forward_kwargs(case, "cuda")
+    kw.update({k: v for k, v in over.items() if k in kw})
+    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], collect=col, **kw)
     torch.cuda.synchronize()
     assert pred is None
     col["noise_pred"] = out
     return col, eng
 
 
-@pytest.mark.parametrize("case_name", ["case_l2", "case_l3"])
+@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22"])
 def test_hip_joint_forward_matches_reference_golden(case_name, request):
     case = request.getfixturevalue(case_name)
     col, _ = _run_hip(case)
