@@ -942,11 +942,30 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & cmask) || (res && ((ldr % 4) || (((uintptr_t)res) & rmask)))) big = false;
     if ((((uintptr_t)bias) | ((uintptr_t)g1) | ((uintptr_t)g0)) & 15) big = false;   // per-column vectors are read 16 B at a time
     if (big) {
+        const int kern = fw_get_option(FW_OPT_GEMM_KERNEL);
+        // Short M tail (VGGT: 32865 rows = 128 full row bands + 97 rows): a 129th band of 256-row tiles costs a whole extra
+        // round of the grid (516 tiles on 256 CUs = 3 rounds for 2.02 rounds of work).  Peel it: the full bands go to the 256x256
+        // kernel (512 tiles = 2 rounds), the <= 128 leftover rows to the 128x128 kernel in a second, tiny launch.  Same
+        // k-order per output element in both kernels, disjoint output rows.
+        const int tail = M % TM;
+        if (kern == 3 && tail > 0 && tail <= BM && M >= 2 * TM) {
+            const int Mfull = M - tail;
+            const size_t cbytes = (out_dtype == FW_DT_F32) ? 4 : 2, rbytes = (res_dtype == FW_DT_F32) ? 4 : 2;
+            int rc = fw_gemm_bf16(A, lda, W, ldw, C, ldc, out_dtype, Mfull, N, K, bias, act, g1, g0, res, ldr, res_dtype, stream);
+            if (rc) return rc;
+            GemmArgs t = p;
+            t.A = A + (int64_t)Mfull * lda;
+            t.C = (char*)C + (size_t)Mfull * ldc * cbytes;
+            t.res = res ? (const char*)res + (size_t)Mfull * ldr * rbytes : nullptr;
+            t.M = tail;
+            t.tiles_m = 1; t.tiles_n = (N + BN - 1) / BN;
+            hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)t.tiles_n), dim3(256), 0, (hipStream_t)stream, t);
+            return (int)hipGetLastError();
+        }
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
         const int var = fw_get_option(FW_OPT_GEMM_VAR);
-        const int kern = fw_get_option(FW_OPT_GEMM_KERNEL);   // 1 = ring (default), 0 = 2-stage staggered
         hipStream_t st = (hipStream_t)stream;
         if (kern == 3 && K >= 4 * BK) {
             if (var == 1) hipLaunchKernelGGL(gemm_bf16_pp_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p);

@@ -22,6 +22,7 @@ import torch
 
 from .config import FWConfig
 from . import rope as _rope
+from .parallel import Ready
 
 
 def _pad_to(t, dim, size):
@@ -45,6 +46,11 @@ class _VggtBlock:
 
 
 class _Bicross:
+    pass
+
+
+class _Stage:
+    """State carried between the begin / mid / end stages of an attention half."""
     pass
 
 
@@ -194,30 +200,55 @@ class FusionEngine:
         return self._tables[key]
 
     # ------------------------------------------------------------------------------------------------ blocks
-    def _dit_attn(self, blk, x, ctx_txt, ctx_img, t_mod, tabs, plucker):
-        """Self-attention + cross-attention (+ camera adapter): DiTBlock.forward up to `return_partial`
-        (wan_video_dit.py:296-306).  x: fp32 residual stream [L, D], updated in place."""
+    # Attention halves are split into begin / mid / end so that, when the forward is sequence-sharded, the exchanges (Pending
+    # objects: RCCL on its side stream) overlap independent work of the OTHER branch: the DiT q|k|v head exchange flies
+    # while the VGGT frame block runs, the VGGT exchange while DiT attention runs, the output exchanges while the other
+    # branch's attention / projections run.  Unsharded, every Pending is Ready and the order of independent ops is immaterial.
+    def _dit_attn_begin(self, blk, x, t_mod, tabs):
+        """LN + modulate, fused q|k|v projection, RMSNorm + RoPE; starts the head exchange (or the K/V all-gather)."""
         cfg, ops, sh = self.cfg, self.ops, self.shard
         D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
-        mod = blk.mod + t_mod                                    # [6, D]: shift/scale/gate msa, shift/scale/gate mlp
-        xn = ops.layernorm(x, scale=mod[1], shift=mod[0], eps=cfg.eps)
+        st = _Stage()
+        st.blk, st.x = blk, x
+        st.mod = blk.mod + t_mod                                 # [6, D]: shift/scale/gate msa, shift/scale/gate mlp
+        xn = ops.layernorm(x, scale=st.mod[1], shift=st.mod[0], eps=cfg.eps)
         qkv = ops.linear(xn, blk.qkv)
-        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        q, k = qkv[:, :D], qkv[:, D:2 * D]
         tab = tabs["dit"] if sh is None else tabs["dit_local"]
         # softmax_scale * log2(e) is folded into q before its bf16 rounding: attention then works in the log2 domain
         ops.qk_prep(q, H, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
                     out_scale=ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab)
-        if sh is not None and sh.heads_divisible(H):
-            # head exchange: my rows / all heads -> all rows / my heads, attention over the full sequence, and back
-            t = sh.rows_to_heads(qkv, 3, sh.dit_counts)          # [L, 3, (H/n)*hd]
-            o = ops.attention(t[:, 0], t[:, 1], t[:, 2], H // sh.world, hd, q_prescaled=True)
-            o = sh.heads_to_rows(o, sh.dit_counts)               # [L/n, D]
+        st.qkv = qkv
+        st.exchange = sh is not None and sh.heads_divisible(H)
+        if st.exchange:      # head exchange: my rows / all heads -> all rows / my heads
+            st.pend = sh.rows_to_heads_async(qkv, 3, sh.dit_counts)
+        elif sh is not None:
+            st.pend = sh.all_gather_rows_async(qkv[:, D:], sh.dit_counts)      # [L, 2D] (k | v) of every rank
         else:
-            if sh is not None:
-                kv = sh.all_gather_rows(qkv[:, D:], sh.dit_counts)   # [L, 2D] (k | v) of every rank
-                k, v = kv[:, :D], kv[:, D:]
-            o = ops.attention(q, k, v, H, hd, q_prescaled=True)
+            st.pend = Ready(None)
+        return st
+
+    def _dit_attn_mid(self, st):
+        """Attention over the full key sequence; starts the inverse exchange of the output."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
+        got = st.pend.wait()
+        if st.exchange:
+            o = ops.attention(got[:, 0], got[:, 1], got[:, 2], H // sh.world, hd, q_prescaled=True)
+            st.pend = sh.heads_to_rows_async(o, sh.dit_counts)                 # [L/n, D]
+        else:
+            k, v = (st.qkv[:, D:2 * D], st.qkv[:, 2 * D:]) if got is None else (got[:, :D], got[:, D:])
+            st.pend = Ready(ops.attention(st.qkv[:, :D], k, v, H, hd, q_prescaled=True))
+        st.qkv = None
+
+    def _dit_attn_end(self, st, ctx_txt, ctx_img, plucker):
+        """o-projection into the stream, then cross-attention (+ camera adapter): DiTBlock.forward up to `return_partial`
+        (wan_video_dit.py:296-306).  x: fp32 residual stream [L, D], updated in place.  Returns the modulation table."""
+        cfg, ops = self.cfg, self.ops
+        D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
+        blk, x, mod = st.blk, st.x, st.mod
+        o = st.pend.wait()
         ops.linear(o, blk.o, g1=mod[2], res=x, out_f32=True, out=x)
         # cross-attention: text + image keys share q; outputs are summed (wan_video_dit.py:185-201)
         xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
@@ -240,6 +271,12 @@ class FusionEngine:
         ops.linear(oc, blk.co, res=x, out_f32=True, out=x)
         return mod
 
+    def _dit_attn(self, blk, x, ctx_txt, ctx_img, t_mod, tabs, plucker):
+        """Self-attention + cross-attention (+ camera adapter), nothing interleaved (the PCB blocks)."""
+        st = self._dit_attn_begin(blk, x, t_mod, tabs)
+        self._dit_attn_mid(st)
+        return self._dit_attn_end(st, ctx_txt, ctx_img, plucker)
+
     def _dit_ffn(self, blk, x, mod):
         """FFN half (`run_remaining`, wan_video_dit.py:288-294)."""
         cfg, ops = self.cfg, self.ops
@@ -247,30 +284,58 @@ class FusionEngine:
         hbuf = ops.linear(xn, blk.ffn0, act="gelu_tanh")
         ops.linear(hbuf, blk.ffn2, g1=mod[5], res=x, out_f32=True, out=x)
 
-    def _vggt_attn(self, blk, tok, e0, tabs, batch, frame_mode):
-        """Attention half of vggt Block.forward (block.py:73-76,99-107).  tok: fp32 [rows, C] in place."""
+    def _vggt_attn_begin(self, blk, tok, e0, tabs, batch, frame_mode):
+        """LN + modulate, fused qkv, per-head LN + 2-D RoPE; global mode starts the head exchange (or the K/V all-gather)."""
         cfg, ops, sh = self.cfg, self.ops, self.shard
         C, H = cfg.vggt_dim, cfg.vggt_heads
         hd = C // H
-        e = blk.mod + e0                                         # [6, C]; e[2] is never used (block.py:73-81)
+        st = _Stage()
+        st.blk, st.x, st.batch = blk, tok, batch
+        st.mod = blk.mod + e0                                    # [6, C]; e[2] is never used (block.py:73-81)
+        e = st.mod
         xn = ops.layernorm(tok, w=blk.norm1[0], b=blk.norm1[1], scale=e[1], shift=e[0], eps=cfg.vggt_eps)
         qkv = ops.linear(xn, blk.qkv)
-        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        q, k = qkv[:, :C], qkv[:, C:2 * C]
         ops.qk_prep(q, H, hd, norm="ln_head", norm_w=blk.q_norm[0], norm_b=blk.q_norm[1], eps=cfg.vggt_eps,
                     rope="half2d", table=tabs["vggt"], out_scale=ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="ln_head", norm_w=blk.k_norm[0], norm_b=blk.k_norm[1], eps=cfg.vggt_eps,
                     rope="half2d", table=tabs["vggt"])
-        if not frame_mode and sh is not None and sh.heads_divisible(H):
-            t = sh.rows_to_heads(qkv, 3, sh.agg_counts)          # global attention: all tokens, my heads
-            o = ops.attention(t[:, 0], t[:, 1], t[:, 2], H // sh.world, hd, batch=1, q_prescaled=True)
-            o = sh.heads_to_rows(o, sh.agg_counts)
+        st.qkv = qkv
+        shard_it = (not frame_mode) and sh is not None
+        st.exchange = shard_it and sh.heads_divisible(H)
+        if st.exchange:
+            st.pend = sh.rows_to_heads_async(qkv, 3, sh.agg_counts)            # global attention: all tokens, my heads
+        elif shard_it:
+            st.pend = sh.all_gather_rows_async(qkv[:, C:], sh.agg_counts)
         else:
-            if not frame_mode and sh is not None:
-                kv = sh.all_gather_rows(qkv[:, C:], sh.agg_counts)
-                k, v = kv[:, :C], kv[:, C:]
-            o = ops.attention(q, k, v, H, hd, batch=batch, q_prescaled=True)
-        ops.linear(o, blk.proj, g1=blk.ls1, res=tok, out_f32=True, out=tok)
-        return e
+            st.pend = Ready(None)
+        return st
+
+    def _vggt_attn_mid(self, st):
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        C, H = cfg.vggt_dim, cfg.vggt_heads
+        hd = C // H
+        got = st.pend.wait()
+        if st.exchange:
+            o = ops.attention(got[:, 0], got[:, 1], got[:, 2], H // sh.world, hd, batch=1, q_prescaled=True)
+            st.pend = sh.heads_to_rows_async(o, sh.agg_counts)
+        else:
+            k, v = (st.qkv[:, C:2 * C], st.qkv[:, 2 * C:]) if got is None else (got[:, :C], got[:, C:])
+            st.pend = Ready(ops.attention(st.qkv[:, :C], k, v, H, hd, batch=st.batch, q_prescaled=True))
+        st.qkv = None
+
+    def _vggt_attn_end(self, st):
+        """x += ls1 * proj(attention) (block.py:73-76,99-107); returns the modulation table for the MLP half."""
+        ops = self.ops
+        o = st.pend.wait()
+        ops.linear(o, st.blk.proj, g1=st.blk.ls1, res=st.x, out_f32=True, out=st.x)
+        return st.mod
+
+    def _vggt_attn(self, blk, tok, e0, tabs, batch, frame_mode):
+        """Attention half of vggt Block.forward, nothing interleaved.  tok: fp32 [rows, C] in place."""
+        st = self._vggt_attn_begin(blk, tok, e0, tabs, batch, frame_mode)
+        self._vggt_attn_mid(st)
+        return self._vggt_attn_end(st)
 
     def _vggt_mlp(self, blk, tok, e):
         """MLP half: x += (ls2(mlp(norm2(x)) * (1 + e4) + e3)) * e5 -- modulation AFTER the MLP (block.py:78-81)."""
@@ -297,11 +362,14 @@ class FusionEngine:
         ops.qk_prep(kv2[:, :Bd], Hb, hd, rope="interleaved", table=tabs["bi_agg"] if sh is None else tabs["bi_agg_local"])
         q_loc, k_loc = qv1[:, :Bd], kv2[:, :Bd]
         if sh is not None:
-            qv1_all = sh.all_gather_rows(qv1, sh.dit_counts)
-            kv2_all = sh.all_gather_rows(kv2, sh.agg_counts)
+            # both gathers in flight together; direction 1 only needs k|v2, so it runs while q|v1 is still arriving
+            p_qv1 = sh.all_gather_rows_async(qv1, sh.dit_counts)
+            p_kv2 = sh.all_gather_rows_async(kv2, sh.agg_counts)
         else:
-            qv1_all, kv2_all = qv1, kv2
+            p_qv1, p_kv2 = Ready(qv1), Ready(kv2)
+        kv2_all = p_kv2.wait()
         o1 = ops.attention(q_loc, kv2_all[:, :Bd], kv2_all[:, Bd:], Hb, hd, q_prescaled=True)      # softmax(q k^T) v2
+        qv1_all = p_qv1.wait()
         o2 = ops.attention(k_loc, qv1_all[:, :Bd], qv1_all[:, Bd:], Hb, hd, q_prescaled=True)      # softmax(k q^T) v1
         ops.linear(o1, bc.out1, g1=bc.gamma1, res=x, out_f32=True, out=x)
         ops.linear(o2, bc.out2, g1=bc.gamma2, res=tok, out_f32=True, out=tok)
@@ -405,13 +473,20 @@ class FusionEngine:
         outputs = {}
         for i in range(cfg.n_irg):
             fb = self.frame[i]
-            e = self._vggt_attn(fb, tok, e0, tabs, batch=S_loc, frame_mode=True)
-            self._vggt_mlp(fb, tok, e)
-            frame_out = tok.clone() if i in need else None
             blk = self.dit[cfg.start_index + i]
             gb = self.glob[i]
-            mod = self._dit_attn(blk, xs, ctx_txt, ctx_img, t_mod, tabs, plucker)
-            e = self._vggt_attn(gb, tok, e0, tabs, batch=1, frame_mode=False)
+            # The DiT block and the VGGT frame/global blocks of an IRG iteration are independent until the bicross
+            # (fusion/layer/block.py:59-74), so their stages are interleaved to hide the exchanges of one branch behind the
+            # compute of the other (same arithmetic as the reference order: frame block, DiT partial, VGGT global partial).
+            sd = self._dit_attn_begin(blk, xs, t_mod, tabs)                     # DiT q|k|v exchange in flight ...
+            e = self._vggt_attn(fb, tok, e0, tabs, batch=S_loc, frame_mode=True)   # ... behind the VGGT frame block
+            self._vggt_mlp(fb, tok, e)
+            frame_out = tok.clone() if i in need else None
+            sg = self._vggt_attn_begin(gb, tok, e0, tabs, batch=1, frame_mode=False)   # VGGT exchange in flight ...
+            self._dit_attn_mid(sd)                                              # ... behind DiT self-attention
+            self._vggt_attn_mid(sg)                                             # DiT output exchange behind VGGT attention
+            mod = self._dit_attn_end(sd, ctx_txt, ctx_img, plucker)             # VGGT output exchange behind DiT cross-attn
+            e = self._vggt_attn_end(sg)
             if i in cfg.cross_attention_list and not uncond:
                 self._bicross(self.bicross[i], xs, tok, tabs)
             self._dit_ffn(blk, xs, mod)

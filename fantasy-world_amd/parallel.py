@@ -35,6 +35,30 @@ def split_counts(n: int, parts: int) -> List[int]:
     return [q + (1 if i < r else 0) for i in range(parts)]
 
 
+class Pending:
+    """A collective in flight.  torch.distributed runs it on the backend's own stream (RCCL: a side HIP stream that first
+    waits for the producer kernels already enqueued on the compute stream); wait() makes the COMPUTE stream wait for it (no
+    host sync) and returns the result.  Everything enqueued between the issue and wait() overlaps the exchange."""
+
+    __slots__ = ("_work", "_finish")
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._finish()
+
+
+class Ready(Pending):
+    """Same interface for a value that needs no communication (single-rank group)."""
+
+    def __init__(self, value):
+        super().__init__(None, lambda: value)
+
+
 class SequenceShard:
     def __init__(self, rank: int, world: int, group=None):
         self.rank, self.world, self.group = rank, world, group
@@ -74,48 +98,59 @@ class SequenceShard:
     def take_dit_rows(self, t):
         return t[self.dit_start:self.dit_start + self.dit_counts[self.rank]].contiguous()
 
-    def all_gather_rows(self, t, counts):
-        """t: this rank's [counts[rank], C] rows (any strides) -> [sum(counts), C] with every rank's rows, in rank order."""
+    def all_gather_rows_async(self, t, counts) -> Pending:
+        """t: this rank's [counts[rank], C] rows (any strides) -> Pending of [sum(counts), C] (every rank's rows, rank order)."""
         assert t.shape[0] == counts[self.rank], (t.shape, counts, self.rank)
         t = t.contiguous()
         C = t.shape[1]
         mx = max(counts)
         if min(counts) == mx:
             out = torch.empty(mx * self.world, C, dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t, group=self.group)
-            return out
+            work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+            return Pending(work, lambda: out)
         pad = torch.zeros(mx, C, dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
         buf = torch.empty(self.world, mx, C, dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(buf.view(self.world * mx, C), pad, group=self.group)
-        return torch.cat([buf[r, : counts[r]] for r in range(self.world)], dim=0)
+        work = dist.all_gather_into_tensor(buf.view(self.world * mx, C), pad, group=self.group, async_op=True)
+        return Pending(work, lambda: torch.cat([buf[r, : counts[r]] for r in range(self.world)], dim=0))
+
+    def all_gather_rows(self, t, counts):
+        return self.all_gather_rows_async(t, counts).wait()
 
     def heads_divisible(self, heads):
         return heads % self.world == 0
 
-    def rows_to_heads(self, t, parts, counts):
+    def rows_to_heads_async(self, t, parts, counts) -> Pending:
         """Head exchange, forward direction.  t: this rank's rows [counts[rank], parts*H*hd] laid out as `parts` blocks of
-        H*hd columns (q|k|v).  Returns [sum(counts), parts, (H/world)*hd]: every rank's rows (rank order = token order) for
-        this rank's H/world heads.  One all_to_all_single with uneven row splits."""
+        H*hd columns (q|k|v).  Pending of [sum(counts), parts, (H/world)*hd]: every rank's rows (rank order = token order)
+        for this rank's H/world heads.  One all_to_all_single with uneven row splits."""
         rows, width = t.shape
         assert rows == counts[self.rank] and width % (parts * self.world) == 0, (t.shape, parts, counts)
         c = width // (parts * self.world)                       # (H/world)*hd
         send = t.reshape(rows, parts, self.world, c).permute(2, 0, 1, 3).contiguous()       # [world, rows, parts, c]
         out = torch.empty(sum(counts), parts, c, dtype=t.dtype, device=t.device)
-        dist.all_to_all_single(out.view(sum(counts), parts * c), send.view(self.world * rows, parts * c),
-                               output_split_sizes=list(counts), input_split_sizes=[rows] * self.world, group=self.group)
-        return out
+        work = dist.all_to_all_single(out.view(sum(counts), parts * c), send.view(self.world * rows, parts * c),
+                                      output_split_sizes=list(counts), input_split_sizes=[rows] * self.world,
+                                      group=self.group, async_op=True)
+        return Pending(work, lambda: out)
 
-    def heads_to_rows(self, o, counts):
+    def rows_to_heads(self, t, parts, counts):
+        return self.rows_to_heads_async(t, parts, counts).wait()
+
+    def heads_to_rows_async(self, o, counts) -> Pending:
         """Inverse exchange for the attention output.  o: [sum(counts), (H/world)*hd] (all rows, my heads) ->
-        [counts[rank], H*hd] (my rows, all heads)."""
+        Pending of [counts[rank], H*hd] (my rows, all heads)."""
         total, c = o.shape
         assert total == sum(counts), (o.shape, counts)
         rows = counts[self.rank]
         recv = torch.empty(self.world * rows, c, dtype=o.dtype, device=o.device)
-        dist.all_to_all_single(recv, o.contiguous(), output_split_sizes=[rows] * self.world,
-                               input_split_sizes=list(counts), group=self.group)
-        return recv.view(self.world, rows, c).permute(1, 0, 2).reshape(rows, self.world * c)
+        src = o.contiguous()
+        work = dist.all_to_all_single(recv, src, output_split_sizes=[rows] * self.world,
+                                      input_split_sizes=list(counts), group=self.group, async_op=True)
+        return Pending(work, lambda: recv.view(self.world, rows, c).permute(1, 0, 2).reshape(rows, self.world * c))
+
+    def heads_to_rows(self, o, counts):
+        return self.heads_to_rows_async(o, counts).wait()
 
     def dit_rows_to_frames(self, ptok, hw):
         """Bridge (model_wan21.py:170-175): patch tokens are produced in the DiT row split but consumed per frame."""
