@@ -853,7 +853,8 @@ __global__ __launch_bounds__(512, 2) void attention_pp2_kernel(AttnArgs p) {
 template <int HD, int VAR>
 __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
     constexpr bool DMA_QK = (VAR & 1) != 0;
-    constexpr bool TIMING = (VAR & 2) != 0;    // measurement build: s_memtime at the segment boundaries of one tile
+    constexpr bool TIMING = (VAR & 2) != 0;
+    constexpr bool NOPIN = (VAR & 4) != 0;     // experiment: let LLVM sink the softmax next to the PV MFMAs (intra-wave interleave)    // measurement build: s_memtime at the segment boundaries of one tile
     constexpr int KS = HD / 16, DB = HD / 32, NCH = HD / 8, NFR = HD / 8;
     constexpr int VT_TILE_BYTES = HD * 128;
     constexpr int VROWS = HD / 16, VLANES = VROWS * 8;
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
             }
         }
         l_run += ls;
-        {   // keep the softmax in THIS segment (LLVM otherwise sinks it behind the barrier, next to the PV MFMAs)
+        if (!NOPIN) {   // keep the softmax in THIS segment (LLVM otherwise sinks it behind the barrier, next to the PV MFMAs)
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pw[i]));
             asm volatile("" : "+v"(l_run));
@@ -1103,12 +1104,13 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
                 }
             }
             // pin the issue order: MFMA, ds_read, MFMA, ds_read, ...
+            if (!NOPIN)
 #pragma unroll
             for (int i = 0; i < NFR + HF; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            if (!DMA_QK) __builtin_amdgcn_sched_group_barrier(0x008, HF, 0);
+            if (!DMA_QK && !NOPIN) __builtin_amdgcn_sched_group_barrier(0x008, HF, 0);
         }
         FW_TS(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1144,6 +1146,442 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
                 }
                 u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
                 *ptr = w;
+            }
+        }
+    }
+}
+
+
+
+// MFMA with explicit register classes for the one-wave-per-SIMD variant, which uses the whole 512-entry register file.
+// hipcc gives every MFMA of such a kernel its C/D operands in the accumulation half, so the scores would need one
+// v_accvgpr_read per exp.  Scores (and the shift they start from) belong in the architectural half, where VALU reads them;
+// output accumulators and Q fragments are MFMA-only and live in the accumulation half.  The hazard recogniser does not look
+// inside inline asm: callers keep >= 8 MFMAs between these and any VALU read of their results, or insert fw_mfma_drain().
+static __device__ __forceinline__ void fw_mfma_s_first(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+static __device__ __forceinline__ void fw_mfma_s_acc(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+static __device__ __forceinline__ void fw_mfma_o_acc(f32x16_t& d, const bf16x8_t& a, const bf16x8_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+static __device__ __forceinline__ void fw_mfma_drain() {
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// attention_sp_kernel: single-stream software pipeline on 32-key half tiles.
+//
+// Why (tools/probes/valu_probe.hip): inside ONE wave's instruction stream, exp + add + cvt + add ride in the shadow of a
+// 32-cycle v_mfma_f32_32x32x16_bf16 almost for free (38 cycles per MFMA), whereas VALU work issued by the SIMD's other wave
+// stretches the partner's MFMAs to ~50 cycles (segment timeline of the ping-pong kernels).  So every wave interleaves, in
+// program order, the softmax of half tile u with the QK^T MFMAs of half tile u+1, and the fragment reads of the next MFMAs
+// with the MFMAs that release their registers:
+//     stage A(u):  S(u+1) = K_half(u+1) Q^T   (HD/16 MFMAs)  ||  exp / sum / pack of S(u),  Vt fragments of half u
+//     stage B(u):  O^T += Vt_half(u) P(u)^T    (HD/16 MFMAs)  ||  K fragments of half u+2,  tile DMA
+// A 32-key half tile keeps the live state small (two 16-register score blocks, one 8-fragment register block shared by K and
+// Vt), so 8 waves x 32 query rows still fit two waves per SIMD (<= 256 registers); the two waves of a SIMD are NOT staggered:
+// each stream alone keeps the matrix pipe ~85 % busy and the pair interleaves at instruction granularity.  One barrier per
+// 64-key tile (4-deep K / Vt LDS rings, K(t+3) and Vt(t+2) requested in iteration t, vmcnt(4) before the barrier).
+// Log2-domain scores (FW_ATTN_Q_PRESCALED), running max folded into the accumulator input, overflow check per half tile.
+// ---------------------------------------------------------------------------------------------------------------
+template <int HD, int VAR>
+__global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void attention_sp_kernel(AttnArgs p) {
+    constexpr bool PINNED = (VAR & 1) != 0;   // sched_group_barrier pins on the stage bodies
+    // timing ablations (results are wrong by construction; tools/microbench.py only, FW_ATTN_VAR = 256 + bits, hd 128):
+    // 4 = no exp, 8 = no fragment reads in the loop, 16 = no tile DMA and no barrier, 32 = no PV MFMAs
+    constexpr bool AB_NOEXP = (VAR & 4) != 0, AB_NODS = (VAR & 8) != 0, AB_NODMA = (VAR & 16) != 0;
+    constexpr bool AB_NOPV = (VAR & 32) != 0, AB_NOQK = false;
+    constexpr int NS = (VAR & 2) ? 2 : 1;     // 32-row sub-blocks per wave: 2 = one wave per SIMD owning 64 query rows
+    constexpr int NW = 8 / NS;                // waves per work-group (256 query rows either way)
+    constexpr int NP = 16 / NW;               // 1 KiB K pieces / Vt pieces each wave requests per tile
+    constexpr int KS = HD / 16, DB = HD / 32, NCH = HD / 8;
+    constexpr int HF = HD / 16;               // MFMAs per sub-block (and fragments) per stage: KS for QK^T, 2*DB for PV
+    constexpr int PPJ = 8 / HF, PREM = 8 - PPJ * HF;   // score pairs pinned behind each QK^T MFMA, and the remainder
+    constexpr int VT_TILE_BYTES = HD * 128;
+    constexpr int VROWS = HD / 16, VLANES = VROWS * 8;
+    constexpr int V_BASE = ARING * K_TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[ARING * K_TILE_BYTES + ARING * VT_TILE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 31, hi = lane >> 5;
+
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
+    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
+    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
+
+    bf16x8_t qf[NS][KS];
+#pragma unroll
+    for (int sb = 0; sb < NS; ++sb) {
+        const int q_row = qb * QB + (wave * NS + sb) * 32 + fi;
+        const uint16_t* src = Qp + (int64_t)min(q_row, p.Lq - 1) * p.ldq + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[sb][ks] = *(const bf16x8_t*)(src + ks * 16);
+    }
+    if (NS == 2) {
+        // move the Q fragments to the accumulation half here, once: otherwise hipcc keeps them in VGPRs through the prologue
+        // and writes each one to a scratch AGPR right in front of the asm MFMA that reads it (a hazard it cannot see)
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(qf[sb][ks]));
+    }
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+
+    // tile DMA: a K tile is 16 pieces of 4 key rows, a Vt tile 16 pieces of HD/16 feature rows; wave w requests pieces w + NW*i
+    unsigned koff[NP];
+    bool kvalid[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int row = (wave + NW * i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (row & 15);
+        kvalid[i] = chunk < NCH;
+        koff[i] = (unsigned)(row * (int)p.ldk + chunk * 8) * 2u;
+    }
+    unsigned voff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int d = min((wave + NW * i) * VROWS + (lane >> 3), HD - 1);
+        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
+        voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
+    }
+    const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
+    auto issue_k = [&](int t, int slot) __attribute__((always_inline)) {
+        const char* kt = Kp + (size_t)t * k_tile_stride;
+        char* k_lds = smem + (slot & (ARING - 1)) * K_TILE_BYTES;
+        const bool last = ragged && t == nt - 1;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            unsigned off = koff[i];
+            if (last) {
+                const int row = (wave + NW * i) * 4 + (lane >> 4);
+                const int over = row - (p.Lk - 1 - (nt - 1) * KVB);
+                if (over > 0) off -= (unsigned)(over * (int)p.ldk) * 2u;
+            }
+            if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + NW * i) * 1024);
+        }
+    };
+    auto issue_v = [&](int t, int slot) __attribute__((always_inline)) {
+        const char* vt = Vp + (size_t)t * (KVB * 2);
+        char* v_lds = smem + V_BASE + (slot & (ARING - 1)) * VT_TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave + NW * i) * (VROWS * 128));
+    };
+
+    int kcoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
+    int vcoff[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) vcoff[s2] = V_BASE + fi * 128 + (((2 * s2 + hi) ^ ((fi >> 1) & 7)) << 4);
+
+    f32x16_t o[NS][DB];
+    f32x16_t negm[NS];
+    float m_run[NS], l_run[NS];
+#pragma unroll
+    for (int sb = 0; sb < NS; ++sb) {
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[sb][d][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[sb][r] = 0.f;
+        m_run[sb] = 0.f;
+        l_run[sb] = 0.f;
+        if (NS == 2) {
+#pragma unroll
+            for (int d = 0; d < DB; ++d) asm volatile("" : "+a"(o[sb][d]));
+        }
+    }
+    bool bad = false;
+    bf16x8_t fr[HF];
+    f32x16_t sA[NS], sB[NS];
+    uint32_t pw[NS][8];
+
+    // K fragments of key block `blk` (0/1) of tile t -> fr
+    auto load_k_half = [&](int t, int blk) __attribute__((always_inline)) {
+        const char* kb = smem + (t & (ARING - 1)) * K_TILE_BYTES + blk * 32 * 256;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fr[ks] = *(const bf16x8_t*)(kb + kcoff[ks]);
+    };
+    // One half tile: `cur` = shifted scores of half u (consumed), `nxt` receives those of half u+1.
+    // NEXT: half u+1 exists;  NEXT2: half u+2 exists;  MASK: last tile (masks the keys beyond Lk when it is ragged).
+    // The shift is the row maximum of the first 32 keys and never moves: exp2 of a log2-domain score minus that anchor stays
+    // a finite float (and a finite bf16) for spreads up to ~2^96, and floating point keeps the relative precision whatever
+    // the magnitude, so there is nothing to rescale.  A half-row sum beyond 2^96 (or a NaN) only raises `bad`; such a wave
+    // recomputes its rows with the exact recurrence after the loop.  The loop body therefore has no data-dependent branch.
+    // Every K / Vt fragment feeds the MFMAs of all NS sub-blocks (NS = 2 halves the LDS reads per MFMA).
+    auto half = [&](f32x16_t (&cur)[NS], f32x16_t (&nxt)[NS], int t, auto hf_tag, auto next_tag, auto next2_tag, auto mask_tag)
+                    __attribute__((always_inline)) {
+        constexpr int hf = decltype(hf_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value, MASK = decltype(mask_tag)::value;
+        if (MASK) {
+            if (ragged) {
+                const int kbase = t * KVB + hf * 32 + 4 * hi;
+#pragma unroll
+                for (int sb = 0; sb < NS; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kbase + (r & 3) + 8 * (r >> 2) >= p.Lk) cur[sb][r] = -1.0e30f;
+            }
+        }
+        const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+        // ---- stage A: QK^T of half u+1 (fr = its K fragments), softmax of half u, Vt fragments of half u into the freed registers
+        float ls[NS];
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) ls[sb] = 0.f;
+#pragma unroll
+        for (int j = 0; j < HF; ++j) {
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) {
+                if (NEXT && !AB_NOQK) {
+                    if (NS == 2) {
+                        if (j == 0) fw_mfma_s_first(nxt[sb], fr[j], qf[sb][j], negm[sb]);
+                        else fw_mfma_s_acc(nxt[sb], fr[j], qf[sb][j]);
+                    } else {
+                        nxt[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j], qf[sb][j], j == 0 ? negm[sb] : nxt[sb], 0, 0, 0);
+                    }
+                }
+                // pairs (2i, 2i+1), i in [8j/HF, 8(j+1)/HF): exp, row sum and bf16 pack ride behind this MFMA
+#pragma unroll
+                for (int i = (8 * j) / HF; i < (8 * (j + 1)) / HF; ++i) {
+                    const float a0 = AB_NOEXP ? cur[sb][2 * i] : __builtin_amdgcn_exp2f(cur[sb][2 * i]);
+                    const float a1 = AB_NOEXP ? cur[sb][2 * i + 1] : __builtin_amdgcn_exp2f(cur[sb][2 * i + 1]);
+                    ls[sb] += a0 + a1;
+                    pw[sb][i] = pack_bf16x2(a0, a1);
+                }
+                if (sb == NS - 1 && !AB_NODS) fr[j] = *(const bf16x8_t*)(vb + (j % DB) * 32 * 128 + vcoff[2 * hf + j / DB]);
+                if (NS == 2) __builtin_amdgcn_sched_barrier(0);      // one MFMA and its fillers per scheduling region
+            }
+        }
+        if (PINNED && NS == 1) {
+#pragma unroll
+            for (int j = 0; j < HF; ++j) {
+                if (NEXT) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read
+                __builtin_amdgcn_sched_group_barrier(0x400, 2 * PPJ, 0);           // TRANS (v_exp)
+                __builtin_amdgcn_sched_group_barrier(0x002, 3 * PPJ, 0);           // VALU (sum, pack)
+            }
+            if (PREM) {
+                __builtin_amdgcn_sched_group_barrier(0x400, 2 * PREM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3 * PREM, 0);
+            }
+        }
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) {
+            bad |= !(ls[sb] <= 0x1p96f);
+            l_run[sb] += ls[sb];
+        }
+        // ---- stage B: PV of half u, K fragments of half u+2 behind the MFMAs
+        const char* kb = smem + ((t + 1) & (ARING - 1)) * K_TILE_BYTES + hf * 32 * 256;      // half u+2 = tile t+1, same block
+#pragma unroll
+        for (int i = 0; i < HF; ++i) {
+            const int ks2 = i / DB, d = i % DB;
+#pragma unroll
+            for (int sb = 0; sb < NS; ++sb) {
+                u32x4_t pv4 = {pw[sb][4 * ks2], pw[sb][4 * ks2 + 1], pw[sb][4 * ks2 + 2], pw[sb][4 * ks2 + 3]};
+                bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+                if (AB_NOPV) asm volatile("" :: "v"(pf));
+                else if (NS == 2) fw_mfma_o_acc(o[sb][d], fr[i], pf);
+                else o[sb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf, o[sb][d], 0, 0, 0);
+            }
+            if (NEXT2 && !AB_NODS) fr[i] = *(const bf16x8_t*)(kb + kcoff[i]);
+            if (NS == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (PINNED && NS == 1) {
+#pragma unroll
+            for (int i = 0; i < HF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (NEXT2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    // one 64-key tile.  The ring slot of K(t+3) held K(t-1) and that of Vt(t+2) held Vt(t-2), both dead; near the end the
+    // requests are clamped to the last tile (they land in slots nobody reads) so the wait count stays a constant.
+    auto tile = [&](int t, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        using NotLast = std::integral_constant<bool, !LAST>;
+        half(sA, sB, t, H0{}, T_{}, NotLast{}, last_tag);
+        if (!LAST && !AB_NODMA) {
+            issue_k(min(t + 3, nt - 1), t + 3);
+            issue_v(min(t + 2, nt - 1), t + 2);
+        }
+        half(sB, sA, t, H1{}, NotLast{}, NotLast{}, last_tag);
+        if (!LAST && !AB_NODMA) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fw_await_vm<2 * NP>();
+            FW_ABARRIER();
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------
+    issue_k(0, 0);
+    issue_k(min(1, nt - 1), 1);
+    issue_k(min(2, nt - 1), 2);
+    issue_v(0, 0);
+    issue_v(min(1, nt - 1), 1);
+    fw_await_vm<0>();
+    FW_ABARRIER();
+    load_k_half(0, 0);
+    if (NS == 2) asm volatile("s_nop 7" ::: "memory");      // VALU-written zero splat -> srcC of the first asm MFMA
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb)
+        {
+            if (NS == 2) {
+                if (ks == 0) fw_mfma_s_first(sA[sb], fr[ks], qf[sb][ks], negm[sb]);
+                else fw_mfma_s_acc(sA[sb], fr[ks], qf[sb][ks]);
+            } else {
+                sA[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks], qf[sb][ks], ks == 0 ? negm[sb] : sA[sb], 0, 0, 0);
+            }
+        }
+    if (NS == 2) fw_mfma_drain();
+    load_k_half(0, 1);                        // K fragments of half 1 for stage A of half 0
+#pragma unroll
+    for (int sb = 0; sb < NS; ++sb) {
+        // anchor: exact row maximum of the first 32 keys (keys beyond Lk excluded)
+        if (ragged && nt == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (4 * hi + (r & 3) + 8 * (r >> 2) >= p.Lk) sA[sb][r] = -1.0e30f;
+        }
+        float mx = fw_max16(sA[sb]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        m_run[sb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sA[sb][r] -= m_run[sb];
+            negm[sb][r] = -m_run[sb];
+        }
+    }
+
+    // the shift splat was just written by VALU and the first asm MFMA reads it as srcC: that hazard is ours to cover
+    if (NS == 2) asm volatile("s_nop 7" ::: "memory");
+    if (nt > 1) {
+        for (int t = 0; t < nt - 1; ++t) tile(t, F_{});
+    }
+    tile(nt - 1, T_{});
+    if (NS == 2) fw_mfma_drain();
+
+    if (__any(bad)) {
+        // ---- exact recomputation of this wave's rows: plain online softmax, fragments straight from global memory.
+        // Only reached when the score spread of a row exceeds ~2^96 in the log2 domain; speed does not matter here.
+        const uint16_t* Kg = (const uint16_t*)Kp;
+        const uint16_t* Vg = (const uint16_t*)Vp;
+#pragma unroll 1
+        for (int sb = 0; sb < NS; ++sb) {
+            f32x16_t oe[DB];
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oe[d][r] = 0.f;
+            float me = -3.0e38f, le = 0.f;
+            bf16x8_t qe[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qe[ks] = sb == 0 ? qf[0][ks] : qf[NS - 1][ks];
+            for (int kb0 = 0; kb0 < p.Lk; kb0 += 32) {
+                f32x16_t sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+                const int krow = min(kb0 + fi, p.Lk - 1);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8_t kf = *(const bf16x8_t*)(Kg + (size_t)krow * p.ldk + ks * 16 + hi * 8);
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qe[ks], sc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb0 + 4 * hi + (r & 3) + 8 * (r >> 2) >= p.Lk) sc[r] = -3.0e38f;
+                float mx = fw_max16(sc);
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])), me);
+                const float alpha = __builtin_amdgcn_exp2f(fmaxf(me - mx, -200.f));
+                me = mx;
+                le *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oe[d][r] *= alpha;
+                uint32_t pq[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float a0 = __builtin_amdgcn_exp2f(fmaxf(sc[2 * i] - mx, -200.f));
+                    const float a1 = __builtin_amdgcn_exp2f(fmaxf(sc[2 * i + 1] - mx, -200.f));
+                    le += a0 + a1;
+                    pq[i] = pack_bf16x2(a0, a1);
+                }
+#pragma unroll
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+                    u32x4_t pv4 = {pq[4 * ks2], pq[4 * ks2 + 1], pq[4 * ks2 + 2], pq[4 * ks2 + 3]};
+                    const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
+#pragma unroll
+                    for (int d = 0; d < DB; ++d) {
+                        const bf16x8_t vf = *(const bf16x8_t*)(Vg + (size_t)(d * 32 + fi) * p.lkp + kb0 + ks2 * 16 + hi * 8);
+                        oe[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oe[d], 0, 0, 0);
+                    }
+                }
+            }
+            if (sb == 0) {
+#pragma unroll
+                for (int d = 0; d < DB; ++d) o[0][d] = oe[d];
+                l_run[0] = le;
+            } else {
+#pragma unroll
+                for (int d = 0; d < DB; ++d) o[NS - 1][d] = oe[d];
+                l_run[NS - 1] = le;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int sb = 0; sb < NS; ++sb) {
+        const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q_row = qb * QB + (wave * NS + sb) * 32 + fi;
+        if (q_row < p.Lq) {
+            uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = d * 32 + 8 * g + 4 * hi;
+                    float v0 = o[sb][d][4 * g + 0] * inv, v1 = o[sb][d][4 * g + 1] * inv;
+                    float v2 = o[sb][d][4 * g + 2] * inv, v3 = o[sb][d][4 * g + 3] * inv;
+                    u32x2_t* ptr = (u32x2_t*)(dst + col);
+                    if (p.accumulate) {
+                        const u32x2_t old = *ptr;
+                        v0 += __uint_as_float(old[0] << 16);
+                        v1 += __uint_as_float(old[0] & 0xffff0000u);
+                        v2 += __uint_as_float(old[1] << 16);
+                        v3 += __uint_as_float(old[1] & 0xffff0000u);
+                    }
+                    u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+                    *ptr = w;
+                }
             }
         }
     }
@@ -1220,10 +1658,36 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
     const int var = fw_get_option(FW_OPT_ATTN_VAR);     // 0 = first kernel; 16 + bits = ping-pong kernel (bit 0 prio, bit 1 deferred rescale)
+    if (prescaled && var >= 128) {
+        // single-stream software pipeline on half tiles; bit 0: pinned issue order, bit 1: one 64-row wave per SIMD
+#define FW_ATTN_SP(HDV, V) \
+    hipLaunchKernelGGL((attention_sp_kernel<HDV, V>), dim3((unsigned)nwg), dim3(((V) & 2) ? 256 : 512), 0, st, p)
+#define FW_ATTN_SP_HD(V) \
+    do { if (head_dim == 128) FW_ATTN_SP(128, V); else if (head_dim == 96) FW_ATTN_SP(96, V); else FW_ATTN_SP(64, V); } while (0)
+        if (var >= 256 && head_dim == 128) {      // timing ablations of the 64-row variant (see the kernel's AB_ flags)
+            switch ((var - 256) & 0x7c) {
+                case 4: FW_ATTN_SP(128, 3 + 4); break;
+                case 8: FW_ATTN_SP(128, 3 + 8); break;
+                case 16: FW_ATTN_SP(128, 3 + 16); break;
+                case 28: FW_ATTN_SP(128, 3 + 28); break;
+                case 32: FW_ATTN_SP(128, 3 + 32); break;
+                default: FW_ATTN_SP(128, 3); break;
+            }
+            return (int)hipGetLastError();
+        }
+        switch (var & 3) {
+            case 0: FW_ATTN_SP_HD(0); break;
+            case 1: FW_ATTN_SP_HD(1); break;
+            case 2: FW_ATTN_SP_HD(2); break;
+            default: FW_ATTN_SP_HD(3); break;
+        }
+        return (int)hipGetLastError();
+    }
     if (prescaled && var >= 64) {
         // fast path: log2-domain scores (var 64: DMA in front of PV, 65: DMA between the QK^T MFMAs)
 #define FW_ATTN_PP3(HDV, V) hipLaunchKernelGGL((attention_pp3_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
-        if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
+        if ((var & 7) == 4) { if (head_dim == 128) FW_ATTN_PP3(128, 4); else if (head_dim == 96) FW_ATTN_PP3(96, 4); else FW_ATTN_PP3(64, 4); }
+        else if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
         else if (var & 1) { if (head_dim == 128) FW_ATTN_PP3(128, 1); else if (head_dim == 96) FW_ATTN_PP3(96, 1); else FW_ATTN_PP3(64, 1); }
         else { if (head_dim == 128) FW_ATTN_PP3(128, 0); else if (head_dim == 96) FW_ATTN_PP3(96, 0); else FW_ATTN_PP3(64, 0); }
         return (int)hipGetLastError();

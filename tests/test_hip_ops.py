@@ -157,7 +157,9 @@ def test_gemv_f32(ops, ref):
 DEFAULT_ATTN_VAR = 64
 
 
-@pytest.fixture(params=[0, 18, 34, 64, 65], ids=["attn_v0", "attn_pp4_defer", "attn_pp2", "attn_pp3", "attn_pp3_dmaqk"])
+@pytest.fixture(params=[0, 18, 34, 64, 65, 128, 129, 131],
+                ids=["attn_v0", "attn_pp4_defer", "attn_pp2", "attn_pp3", "attn_pp3_dmaqk", "attn_sp", "attn_sp_pinned",
+                     "attn_sp_w4"])
 def attn_variant(ops, request):
     """Every attention test runs on the first kernel (0), on the 4- and 2-segment ping-pong kernels, and on the fast
     log2-domain kernel (64+), which is selected when q carries the softmax scale (q_prescaled=True)."""
