@@ -95,3 +95,24 @@ def plumbing(num_layers: int = 2, start_index: int = 1, ffn_dim: int = 13824) ->
     n_irg = num_layers - start_index
     return FWConfig(num_layers=num_layers, start_index=start_index, ffn_dim=ffn_dim,
                     cross_attention_list=list(range(n_irg)))
+
+
+@dataclass
+class HeadsConfig:
+    """VGGT geometry heads (vggt/models/vggt.py:31-34 constructor arguments)."""
+    dim_in: int = 2048                 # 2 * vggt_dim (frame | global intermediates concatenated)
+    trunk_depth: int = 4               # camera_head.py:30
+    cam_heads: int = 16
+    cam_mlp_ratio: int = 4
+    features: int = 256                # dpt_head.py:43
+    out_channels: List[int] = field(default_factory=lambda: [256, 512, 1024, 1024])
+    layer_idx: List[int] = field(default_factory=lambda: [23, 17, 11, 7])
+    dpt_patch: int = 16                # vggt.py:26 DPT_patch_size
+    depth_out: int = 2                 # depth + confidence (vggt.py:32)
+    point_out: int = 4                 # xyz + confidence (vggt.py:33)
+
+    @staticmethod
+    def small():
+        """Reduced widths for CPU tests (same structure; the reference modules take these as constructor arguments)."""
+        return HeadsConfig(dim_in=128, trunk_depth=2, cam_heads=2, features=64, out_channels=[64, 64, 128, 128],
+                           layer_idx=[3, 2, 1, 0], dpt_patch=4)

@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import torch
 
-from .config import FWConfig
+from .config import FWConfig, HeadsConfig
 
 
 def _lin(spec, name, n_out, n_in, gain=1.0):
@@ -189,4 +189,99 @@ def make_inputs(cfg: FWConfig, f: int, h2: int, w2: int, seed=1, device="cpu", d
         else:
             # round to bf16-representable values: what the reference's bf16 inference path feeds joint_forward
             out[k] = v.to(torch.bfloat16).to(dtype).to(device)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# VGGT geometry heads: vggt/heads/camera_head.py, vggt/heads/dpt_head.py, wan/modules/vae_modified.py
+# ---------------------------------------------------------------------------------------------------------------
+def _conv(spec, name, shape, bias=True, gain=1.0):
+    fan_in = 1
+    for d in shape[1:]:
+        fan_in *= d
+    spec[name + ".weight"] = (tuple(shape), ("normal", gain / math.sqrt(fan_in)))
+    if bias:
+        spec[name + ".bias"] = ((shape[0],), ("normal", 0.02))
+
+
+def heads_weight_spec(hc: HeadsConfig) -> "OrderedDict[str, tuple]":
+    """name -> (shape, init) for vggt.camera_head / vggt.depth_head / vggt.point_head (reference parameter names).
+    LayerScale gammas, the empty pose token and the pose-embedding are drawn at working scale (the reference initialises
+    them at 0.01 / zeros, which would hide the trunk from a parity test)."""
+    spec = OrderedDict()
+    C = hc.dim_in
+    p = "vggt.camera_head."
+    for b in range(hc.trunk_depth):
+        q = f"{p}trunk.{b}."
+        spec[q + "modulation"] = ((1, 6, C), ("normal", 1.0 / math.sqrt(C)))          # unused by the head (block.py:60)
+        spec[q + "norm1.weight"] = ((C,), ("ones_normal", 0.1))
+        spec[q + "norm1.bias"] = ((C,), ("normal", 0.05))
+        _lin(spec, q + "attn.qkv", 3 * C, C)
+        _lin(spec, q + "attn.proj", C, C)
+        spec[q + "ls1.gamma"] = ((C,), ("normal", 0.3))
+        spec[q + "norm2.weight"] = ((C,), ("ones_normal", 0.1))
+        spec[q + "norm2.bias"] = ((C,), ("normal", 0.05))
+        _lin(spec, q + "mlp.fc1", C * hc.cam_mlp_ratio, C)
+        _lin(spec, q + "mlp.fc2", C, C * hc.cam_mlp_ratio)
+        spec[q + "ls2.gamma"] = ((C,), ("normal", 0.3))
+    for n in ("token_norm", "trunk_norm"):
+        spec[p + n + ".weight"] = ((C,), ("ones_normal", 0.1))
+        spec[p + n + ".bias"] = ((C,), ("normal", 0.05))
+    spec[p + "empty_pose_tokens"] = ((1, 1, 9), ("normal", 0.5))
+    _lin(spec, p + "embed_pose", C, 9)
+    _lin(spec, p + "poseLN_modulation.1", 3 * C, C, gain=0.5)
+    _conv(spec, p + "camera_time_upsample.expand_channels", (4 * C, C, 1))
+    _lin(spec, p + "pose_branch.fc1", C // 2, C)
+    _lin(spec, p + "pose_branch.fc2", 9, C // 2)
+    for head, odim in (("vggt.depth_head.", hc.depth_out), ("vggt.point_head.", hc.point_out)):
+        spec[head + "norm.weight"] = ((C,), ("ones_normal", 0.1))
+        spec[head + "norm.bias"] = ((C,), ("normal", 0.05))
+        oc = hc.out_channels
+        for i, c in enumerate(oc):
+            _conv(spec, head + f"projects.{i}", (c, C, 1, 1))
+        _conv(spec, head + "resize_layers.0", (oc[0], oc[0], 4, 4), gain=4.0)     # ConvTranspose2d: [in, out, k, k], k*k taps disjoint
+        _conv(spec, head + "resize_layers.1", (oc[1], oc[1], 2, 2), gain=2.0)
+        _conv(spec, head + "resize_layers.3", (oc[3], oc[3], 3, 3))
+        for i, c in enumerate(oc):
+            t = head + f"temporal_upsamplers.{i}."
+            _conv(spec, t + "conv2", (c, c, 1, 1, 1))
+            for u in (0, 2):
+                _conv(spec, t + f"decoder.upsamples.{u}.time_conv", (2 * c, c, 3, 1, 1))
+            for u in (1, 3):
+                spec[t + f"decoder.upsamples.{u}.residual.0.gamma"] = ((c, 1, 1, 1), ("ones_normal", 0.1))
+                _conv(spec, t + f"decoder.upsamples.{u}.residual.2", (c, c, 3, 3, 3))
+        sc = head + "scratch."
+        f = hc.features
+        for i, c in enumerate(oc):
+            _conv(spec, sc + f"layer{i + 1}_rn", (f, c, 3, 3), bias=False)
+        for r in (1, 2, 3, 4):
+            q = sc + f"refinenet{r}."
+            _conv(spec, q + "out_conv", (f, f, 1, 1))
+            for u in ((1, 2) if r != 4 else (2,)):
+                _conv(spec, q + f"resConfUnit{u}.conv1", (f, f, 3, 3))
+                _conv(spec, q + f"resConfUnit{u}.conv2", (f, f, 3, 3))
+        _conv(spec, sc + "output_conv1", (f // 2, f, 3, 3))
+        _conv(spec, sc + "output_conv2.0", (32, f // 2, 3, 3))
+        _conv(spec, sc + "output_conv2.2", (odim, 32, 1, 1), gain=0.5)
+    return spec
+
+
+def make_heads_weights(hc: HeadsConfig, device="cpu", dtype=torch.float32, seed=0, bf16_round=True):
+    out = OrderedDict()
+    for name, (shape, init) in heads_weight_spec(hc).items():
+        t = make_param(name, shape, init, device=device, dtype=torch.float32, seed=seed)
+        if bf16_round:
+            t = t.to(torch.bfloat16).to(torch.float32)
+        out[name] = t.to(dtype)
+    return out
+
+
+def make_output_list(hc: HeadsConfig, S: int, ph: int, pw: int, n_special=5, seed=3, device="cpu"):
+    """Synthetic aggregator output_list: layer -> fp32 [S, n_special + ph*pw, dim_in], unit-scale tokens (the residual
+    streams of the aggregator are O(1)-O(10); the heads normalise them first)."""
+    need = sorted(set(hc.layer_idx) | {max(hc.layer_idx)})
+    out = {}
+    for layer in need:
+        g = torch.Generator(device="cpu").manual_seed(1000 * seed + layer)
+        out[layer] = (torch.randn(S, n_special + ph * pw, hc.dim_in, generator=g) * 2.0).to(device)
     return out

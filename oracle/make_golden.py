@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from fantasy_world_amd import config as fwc, synth   # noqa: E402
-from oracle import fw_oracle, ref_harness            # noqa: E402
+from oracle import fw_oracle, fw_heads_oracle, ref_harness   # noqa: E402
 
 CASES = {
     # name: (cfg kwargs, (f, h2, w2), timestep, text_len, uncond)
@@ -25,6 +25,13 @@ CASES = {
     "wan21_l3_f2_12x8": (dict(num_layers=3, start_index=1), (2, 12, 8), 937.5, 512, False),
     # Wan2.2-Fun-A14B-Control-Camera flavour (model_wan22.py): control adapter in patchify, text-only context, no per-block adapter
     "wan22_l2_f2_8x12": (dict(num_layers=2, start_index=1), (2, 8, 12), 968.75, 512, False),
+}
+
+
+# geometry heads, reduced widths (HeadsConfig.small()): name -> (S, ph, pw)
+HEAD_CASES = {
+    "heads_small_s3_4x6": (3, 4, 6),
+    "heads_small_s2_5x3": (2, 5, 3),
 }
 
 
@@ -99,6 +106,27 @@ def main():
         print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def main_heads(only):
+    for name, (S, ph, pw) in HEAD_CASES.items():
+        if only and name not in only:
+            continue
+        hc = fwc.HeadsConfig.small()
+        W = synth.make_heads_weights(hc)
+        ol = synth.make_output_list(hc, S, ph, pw)
+        vggt = ref_harness.build_reference_heads(hc, W)
+        t0 = time.time()
+        ref = ref_harness.run_reference_heads(vggt, ol, S, ph, pw, max(hc.layer_idx) + 1)
+        print(f"[{name}] reference heads {time.time()-t0:.1f}s ({sum(v.numel() for v in W.values())/1e6:.1f} M params)")
+        orc = fw_heads_oracle.head_prediction(W, ol, hc, S, ph, pw)
+        for k in ref:
+            print(f"   oracle vs reference  {k:18s} rel-L2 = {rel(orc[k], ref[k]):.3e}   shape {tuple(ref[k].shape)}")
+        golden = {k: v.to(torch.float32).contiguous() for k, v in ref.items()}
+        golden["meta"] = dict(grid=(S, ph, pw), seed_weights=0, seed_tokens=3, torch=torch.__version__, heads="small")
+        path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+        torch.save(golden, path)
+        print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def _cold(name):
     """Parameters that are not on the per-step hot path (geometry heads, pose encoder, CamTokenProjector)."""
     return (name.startswith("vggt.camera_head") or name.startswith("vggt.depth_head") or
@@ -107,4 +135,6 @@ def _cold(name):
 
 
 if __name__ == "__main__":
-    main()
+    if not sys.argv[1:] or any(not a.startswith("heads") for a in sys.argv[1:]):
+        main()
+    main_heads([a for a in sys.argv[1:] if a.startswith("heads")] if sys.argv[1:] else [])

@@ -292,3 +292,40 @@ def _resolve(model, dotted):
     for p in parts[:-1]:
         mod = getattr(mod, p)
     return mod, parts[-1]
+
+
+def build_reference_heads(hc, weights):
+    """The reference's geometry heads (vggt/models/vggt.py:31-34) at the widths of `hc` (fantasy_world_amd.config.HeadsConfig),
+    hung on a bare VGGT so that `_head_predction` (vggt.py:134-154) can be called; `weights`: name -> tensor with the
+    reference's parameter names (prefix "vggt.")."""
+    install_stubs()
+    from FantasyWorld.vggt.models.vggt import VGGT
+    from FantasyWorld.vggt.heads.camera_head import CameraHead
+    from FantasyWorld.vggt.heads.dpt_head import DPTHead_3D_Causal
+
+    vggt = VGGT.__new__(VGGT)
+    nn.Module.__init__(vggt)
+    vggt.camera_head = CameraHead(dim_in=hc.dim_in, trunk_depth=hc.trunk_depth, num_heads=hc.cam_heads,
+                                  mlp_ratio=hc.cam_mlp_ratio)
+    kw = dict(dim_in=hc.dim_in, patch_size=hc.dpt_patch, features=hc.features, out_channels=list(hc.out_channels),
+              intermediate_layer_idx=list(hc.layer_idx))
+    vggt.depth_head = DPTHead_3D_Causal(output_dim=hc.depth_out, activation="exp", conf_activation="expp1", **kw)
+    vggt.point_head = DPTHead_3D_Causal(output_dim=hc.point_out, activation="inv_log", conf_activation="expp1", **kw)
+    vggt.track_head = None
+    holder = nn.Module()
+    holder.vggt = vggt
+    missing, unused = load_named_weights(holder, weights)
+    assert not missing and not unused, (missing[:5], unused[:5])
+    return vggt.eval()
+
+
+def run_reference_heads(vggt, output_list, S, ph, pw, n_layers, patch_start_idx=5):
+    """output_list: layer -> [S, P, 2C]; returns the reference's prediction dict (fp32, CPU; the autocast inside
+    _head_predction is a CUDA autocast and is inert without a GPU)."""
+    import warnings
+    some = next(iter(output_list.values()))
+    agg = [output_list.get(i, torch.zeros_like(some))[None] for i in range(n_layers)]
+    images = torch.zeros(1, S, ph, pw, 1)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return vggt._head_predction(images, patch_start_idx, agg)

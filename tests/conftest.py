@@ -66,3 +66,26 @@ def forward_kwargs(case, dev=None):
     if ins.get("control_camera_latents_input") is not None:
         kw["control_camera_latents_input"] = mv(ins["control_camera_latents_input"])
     return kw
+
+
+class HeadsCase:
+    """Geometry-head golden case: reduced-width heads, weights and tokens regenerated from seeds, the
+    REAL reference's prediction dict from disk (oracle/make_golden.py)."""
+
+    def __init__(self, name):
+        from fantasy_world_amd import config as fwc, synth
+        self.name = name
+        self.golden = load_golden(name)
+        meta = self.golden["meta"]
+        self.hc = fwc.HeadsConfig.small()
+        self.S, self.ph, self.pw = meta["grid"]
+        self.weights = synth.make_heads_weights(self.hc, seed=meta["seed_weights"])
+        self.output_list = synth.make_output_list(self.hc, self.S, self.ph, self.pw, seed=meta["seed_tokens"])
+
+
+@pytest.fixture(scope="session", params=["heads_small_s3_4x6", "heads_small_s2_5x3"])
+def heads_case(request):
+    return HeadsCase(request.param)
+
+
+PRED_KEYS = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")

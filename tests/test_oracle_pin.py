@@ -19,3 +19,34 @@ def test_oracle_matches_reference_golden(case_name, request):
     for k in ("x_after_pcb", "x_final", "tokens_final", "noise_pred"):
         err = rel_l2(col[k], case.golden[k])
         assert err < 5e-6, f"{case.name}:{k} oracle deviates from the reference golden: rel-L2 {err:.3e}"
+
+
+def test_heads_oracle_matches_reference_golden(heads_case):
+    """oracle/fw_heads_oracle.py reproduces the prediction dict of the real VGGT._head_predction (vggt.py:134-154)."""
+    from conftest import PRED_KEYS
+    from oracle import fw_heads_oracle
+    c = heads_case
+    pred = fw_heads_oracle.head_prediction(c.weights, c.output_list, c.hc, c.S, c.ph, c.pw)
+    for k in PRED_KEYS:
+        assert pred[k].shape == c.golden[k].shape, (k, pred[k].shape, c.golden[k].shape)
+        err = rel_l2(pred[k], c.golden[k])
+        assert err < 5e-6, f"{c.name}:{k} heads oracle deviates from the reference golden: rel-L2 {err:.3e}"
+
+
+def test_heads_oracle_matches_live_reference():
+    """In the build container (reference mounted): a third grid, straight against the reference modules, which decode
+    time frame by frame through the convolution cache -- the oracle's whole-sequence causal convolutions must agree."""
+    import os
+    if not os.path.isdir("/root/reference/FantasyWorld"):
+        pytest.skip("reference not mounted on this machine")
+    from conftest import PRED_KEYS
+    from fantasy_world_amd import config as fwc, synth
+    from oracle import fw_heads_oracle, ref_harness
+    hc = fwc.HeadsConfig.small()
+    W = synth.make_heads_weights(hc, seed=5)
+    S, ph, pw = 4, 3, 4
+    ol = synth.make_output_list(hc, S, ph, pw, seed=9)
+    ref = ref_harness.run_reference_heads(ref_harness.build_reference_heads(hc, W), ol, S, ph, pw, max(hc.layer_idx) + 1)
+    pred = fw_heads_oracle.head_prediction(W, ol, hc, S, ph, pw)
+    for k in PRED_KEYS:
+        assert rel_l2(pred[k], ref[k]) < 5e-6, k
