@@ -197,3 +197,71 @@ class TorchRefOps:
 
     def cast_act(self, x):
         return self._r(x.clone())
+
+    # ---- geometry heads: channels-last activations [T*H*W, C] ------------------------------------
+    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False):
+        """Gather for a convolution as GEMM: x [T*H*W, C] -> [nt*Ho*Wo, kt*kh*kw*C] for output frames t0..t0+nt-1, column
+        ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][y*sh + dy - kh//2][x*sw + dx - kw//2][c], zero outside (causal
+        in time: vae_modified.py:17-36; 'same' padding in space)."""
+        C = x.shape[1]
+        nt = T - t0 if nt is None else nt
+        v = x.to(torch.float32).view(T, H, W, C)
+        if relu_in:
+            v = F.relu(v)
+        v = F.pad(v, (0, 0, kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0))
+        Ho, Wo = (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1
+        cols = []
+        for dt in range(kt):
+            for dy in range(kh):
+                for dx in range(kw):
+                    cols.append(v[t0 + dt:t0 + dt + nt, dy:dy + (Ho - 1) * sh + 1:sh, dx:dx + (Wo - 1) * sw + 1:sw])
+        return self._r(torch.cat(cols, dim=-1).reshape(nt * Ho * Wo, kt * kh * kw * C))
+
+    def resize_bilinear(self, x, N, h, w, H, W):
+        """F.interpolate(mode='bilinear', align_corners=True) on [N*h*w, C] -> [N*H*W, C] (dpt_head.py:538-566)."""
+        C = x.shape[1]
+        v = x.to(torch.float32).view(N, h, w, C).permute(0, 3, 1, 2)
+        v = F.interpolate(v, size=(H, W), mode="bilinear", align_corners=True)
+        return self._r(v.permute(0, 2, 3, 1).reshape(N * H * W, C))
+
+    def chan_rmsnorm_silu(self, x, gamma, c_true):
+        """SiLU(F.normalize(x, dim=channel) * sqrt(C) * gamma) (vae_modified.py:39-54, :201-203); padded channels are zero."""
+        v = x.to(torch.float32)
+        y = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12) * (c_true ** 0.5) * gamma
+        return self._r(F.silu(y))
+
+    def depth_to_space(self, y, N, h, w, k, C):
+        """[N*h*w, k*k*C] with column (dy*k + dx)*C + c -> [N*(h*k)*(w*k), C] (ConvTranspose2d with kernel = stride)."""
+        v = y.view(N, h, w, k, k, C).permute(0, 1, 3, 2, 4, 5)
+        return v.reshape(N * h * k * w * k, C).contiguous()
+
+    def add_table(self, x, table):
+        """x [N*hw, C] += table [hw, C] (fp32), in place (positional embedding, dpt_head.py:262-283)."""
+        hw = table.shape[0]
+        x.copy_(self._r((x.to(torch.float32).view(-1, hw, x.shape[1]) + table).view(x.shape)))
+        return x
+
+    def unfold_time2(self, y, n, hw, C):
+        """[n*hw, 2C] -> [2n*hw, C]: columns [0:C] are frame 2i, [C:2C] frame 2i+1 (vae_modified.py:121-124)."""
+        return y.view(n, hw, 2, C).permute(0, 2, 1, 3).reshape(2 * n * hw, C).contiguous()
+
+    def add_act(self, a, b=None, relu=False, out_f32=False):
+        y = a.to(torch.float32) if b is None else a.to(torch.float32) + b.to(torch.float32)
+        if relu:
+            y = F.relu(y)
+        return y if out_f32 else self._r(y)
+
+    def adaln_rows(self, x, mod):
+        """gate * (LN(x) * (1 + scale) + shift) + x with per-row shift|scale|gate = mod [rows, 3C] (camera_head.py:124-128)."""
+        C = x.shape[1]
+        shift, scale, gate = mod[:, :C], mod[:, C:2 * C], mod[:, 2 * C:]
+        return gate * (F.layer_norm(x, (C,), None, None, 1e-6) * (1 + scale) + shift) + x
+
+    def head_activation(self, y, mode):
+        """activate_head / activate_pose (head_act.py): y fp32 [rows, n].  'exp' | 'inv_log': (pts [rows, n-1], 1+exp(conf));
+        'pose': ReLU on columns 7.. (camera_head.py:38)."""
+        if mode == "pose":
+            return torch.cat([y[:, :7], F.relu(y[:, 7:])], dim=-1)
+        xyz, conf = y[:, :-1], y[:, -1]
+        pts = torch.exp(xyz) if mode == "exp" else torch.sign(xyz) * torch.expm1(xyz.abs())
+        return pts, 1 + conf.exp()
