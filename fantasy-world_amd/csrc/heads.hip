@@ -1,0 +1,323 @@
+// Geometry-head kernels of libfw_mi355x.so: the data-movement and pointwise pieces around fw_gemm_bf16
+// for the DPT heads, their temporal up-sampler and the camera head.  Every feature map is a channels-last matrix
+// [frames*H*W][C] in bf16 (C a multiple of 8), so all of these are HBM-bound streaming kernels: 16-byte accesses along C,
+// one work-item per 8 channels, no LDS.  They run once per generation (the last denoising step).
+#include "fw_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(v[i] << 16);
+        f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+__device__ __forceinline__ u32x4_t relu8(u32x4_t v) {
+    // bf16 pairs: clear a half-word when its sign bit is set
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t w = v[i];
+        if (w & 0x00008000u) w &= 0xffff0000u;
+        if (w & 0x80000000u) w &= 0x0000ffffu;
+        v[i] = w;
+    }
+    return v;
+}
+
+// Gather for a convolution as GEMM (Conv2d 3x3 stride 1/2, CausalConv3d (3,1,1) and 3x3x3: dpt_head.py:66-131,
+// vae_modified.py:17-36).  out[(t-t0, yo, xo)][((dt*kh + dy)*kw + dx)*C + c] = x[t + dt - (kt-1)][yo*sh + dy - kh/2][xo*sw + dx - kw/2][c],
+// zero outside the volume: causal in time, 'same' in space.  One work-item per (output row, tap, 8 channels).
+__global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                     int64_t ldo, int C8, int T, int H, int W, int Ho, int Wo, int kt, int kh,
+                                                     int kw, int sh, int sw, int t0, int64_t total, int relu_in) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % C8);
+    int64_t r = gid / C8;
+    const int taps = kt * kh * kw;
+    const int tap = (int)(r % taps);
+    r /= taps;                                           // output row
+    const int xo = (int)(r % Wo);
+    const int yo = (int)((r / Wo) % Ho);
+    const int tt = (int)(r / ((int64_t)Wo * Ho));
+    const int dx = tap % kw, dy = (tap / kw) % kh, dt = tap / (kw * kh);
+    const int ti = t0 + tt + dt - (kt - 1);
+    const int yi = yo * sh + dy - kh / 2;
+    const int xi = xo * sw + dx - kw / 2;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (ti >= 0 && ti < T && yi >= 0 && yi < H && xi >= 0 && xi < W) {
+        v = *(const u32x4_t*)(x + (((int64_t)ti * H + yi) * W + xi) * ldx + c8 * 8);
+        if (relu_in) v = relu8(v);
+    }
+    *(u32x4_t*)(out + r * ldo + ((int64_t)tap * C8 + c8) * 8) = v;
+}
+
+// F.interpolate(mode="bilinear", align_corners=True) on channels-last maps (dpt_head.py:538-566): source coordinate
+// = dst * (in-1)/(out-1), fp32 blend of the four neighbours, one bf16 rounding.
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                              int64_t ldo, int C8, int h, int w, int H, int W, float sy, float sx,
+                                                              int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % C8);
+    const int64_t r = gid / C8;
+    const int X = (int)(r % W), Y = (int)((r / W) % H);
+    const int64_t n = r / ((int64_t)W * H);
+    const float fy = Y * sy, fx = X * sx;
+    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const uint16_t* base = x + (n * h * w) * ldx + c8 * 8;
+    float a[8], b[8], c[8], d[8], o[8];
+    unpack8(*(const u32x4_t*)(base + ((int64_t)y0 * w + x0) * ldx), a);
+    unpack8(*(const u32x4_t*)(base + ((int64_t)y0 * w + x1) * ldx), b);
+    unpack8(*(const u32x4_t*)(base + ((int64_t)y1 * w + x0) * ldx), c);
+    unpack8(*(const u32x4_t*)(base + ((int64_t)y1 * w + x1) * ldx), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float top = a[i] + (b[i] - a[i]) * wx, bot = c[i] + (d[i] - c[i]) * wx;
+        o[i] = top + (bot - top) * wy;
+    }
+    *(u32x4_t*)(out + r * ldo + c8 * 8) = pack8(o);
+}
+
+// SiLU(x / max(|x|_2, 1e-12) * sqrt(c_true) * gamma) over the channel axis (RMS_norm + SiLU of ResidualBlock_Half,
+// vae_modified.py:39-54, 201-203).  One wave per row; padded channels are zero on input and stay zero (gamma padded with 0).
+__global__ __launch_bounds__(256) void chan_rmsnorm_silu_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                                int64_t ldo, int64_t rows, int C, float scale,
+                                                                const float* __restrict__ gamma) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t* src = x + row * ldx;
+    float ss = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+        float f[8];
+        unpack8(*(const u32x4_t*)(src + c), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+    }
+    ss = wave_sum(ss);
+    const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);
+    uint16_t* dst = out + row * ldo;
+    for (int c = lane * 8; c < C; c += 512) {
+        float f[8];
+        unpack8(*(const u32x4_t*)(src + c), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fw_silu(f[i] * inv * gamma[c + i]);
+        *(u32x4_t*)(dst + c) = pack8(f);
+    }
+}
+
+// ConvTranspose2d with kernel = stride = k after its GEMM: y[(n, yy, xx)][(dy*k + dx)*C + c] -> out[(n, yy*k + dy, xx*k + dx)][c]
+__global__ __launch_bounds__(256) void depth_to_space_kernel(const uint16_t* __restrict__ y, int64_t ldy, uint16_t* __restrict__ out,
+                                                             int64_t ldo, int C8, int h, int w, int k, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % C8);
+    const int64_t r = gid / C8;                           // output row
+    const int W = w * k, H = h * k;
+    const int X = (int)(r % W), Y = (int)((r / W) % H);
+    const int64_t n = r / ((int64_t)W * H);
+    const int xx = X / k, dx = X % k, yy = Y / k, dy = Y % k;
+    const u32x4_t v = *(const u32x4_t*)(y + ((n * h + yy) * w + xx) * ldy + ((int64_t)(dy * k + dx) * C8 + c8) * 8);
+    *(u32x4_t*)(out + r * ldo + c8 * 8) = v;
+}
+
+// x[(n, p)][c] += table[p][c]: the UV positional embedding, identical for every frame (dpt_head.py:262-283)
+__global__ __launch_bounds__(256) void add_table_kernel(uint16_t* __restrict__ x, int64_t ldx, const float* __restrict__ table,
+                                                        int C8, int hw, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % C8);
+    const int64_t r = gid / C8;
+    const float* t = table + (r % hw) * (int64_t)(C8 * 8) + c8 * 8;
+    uint16_t* p = x + r * ldx + c8 * 8;
+    float f[8];
+    unpack8(*(const u32x4_t*)p, f);
+    const f32x4_t t0 = *(const f32x4_t*)t, t1 = *(const f32x4_t*)(t + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[i] += t0[i];
+        f[4 + i] += t1[i];
+    }
+    *(u32x4_t*)p = pack8(f);
+}
+
+// temporal up-sampler: y[(i, p)][j*C + c] -> out[(2i + j, p)][c]  (vae_modified.py:121-124)
+__global__ __launch_bounds__(256) void unfold_time2_kernel(const uint16_t* __restrict__ y, int64_t ldy, uint16_t* __restrict__ out,
+                                                           int64_t ldo, int C8, int hw, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % C8);
+    const int64_t r = gid / C8;                           // output row = (2i + j)*hw + p
+    const int64_t p = r % hw, f = r / hw;
+    const int64_t i = f >> 1, j = f & 1;
+    *(u32x4_t*)(out + r * ldo + c8 * 8) = *(const u32x4_t*)(y + (i * hw + p) * ldy + (j * C8 + c8) * 8);
+}
+
+// out = relu?(a + b) on contiguous bf16 tensors (b may be null): the FeatureFusionBlock sum that the next
+// ResidualConvUnit's in-place ReLU rewrites (dpt_head.py:517-522, 440)
+__global__ __launch_bounds__(256) void add_act_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                      uint16_t* __restrict__ out, int64_t n8, int relu) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n8) return;
+    float fa[8], fb[8];
+    unpack8(*(const u32x4_t*)(a + gid * 8), fa);
+    if (b) {
+        unpack8(*(const u32x4_t*)(b + gid * 8), fb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] += fb[i];
+    }
+    if (relu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = fmaxf(fa[i], 0.f);
+    }
+    *(u32x4_t*)(out + gid * 8) = pack8(fa);
+}
+
+// camera head AdaLN (camera_head.py:124-128): out = gate * (LN(x) * (1 + scale) + shift) + x, per-row shift | scale | gate in
+// mod[row][3C], no affine, fp32 throughout.  One wave per row.
+__global__ __launch_bounds__(256) void adaln_rows_kernel(const float* __restrict__ x, const float* __restrict__ mod,
+                                                         float* __restrict__ out, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* src = x + (int64_t)row * C;
+    float s = 0.f, ss = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = src[c];
+        s += v;
+        ss += v * v;
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    const float mean = s / C;
+    const float rstd = rsqrtf(fmaxf(ss / C - mean * mean, 0.f) + eps);
+    const float* m = mod + (int64_t)row * 3 * C;
+    for (int c = lane; c < C; c += 64) {
+        const float v = src[c];
+        out[(int64_t)row * C + c] = m[2 * C + c] * ((v - mean) * rstd * (1.f + m[C + c]) + m[c]) + v;
+    }
+}
+
+// activate_head / activate_pose (head_act.py:11-33, 61-125): y [rows][n] fp32.
+//   mode 0 "exp":     pts = exp(y[:, :n-1]),                       conf = 1 + exp(y[:, n-1])
+//   mode 1 "inv_log": pts = sign(v) * expm1(|v|),                  conf = 1 + exp(y[:, n-1])
+//   mode 2 "pose":    pts[:, :n] = y with ReLU on columns >= 7 (translation, quaternion linear; field of view ReLU)
+__global__ __launch_bounds__(256) void head_activation_kernel(const float* __restrict__ y, int64_t rows, int n, int mode,
+                                                              float* __restrict__ pts, float* __restrict__ conf) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* src = y + r * n;
+    if (mode == 2) {
+        for (int c = 0; c < n; ++c) pts[r * n + c] = c >= 7 ? fmaxf(src[c], 0.f) : src[c];
+        return;
+    }
+    for (int c = 0; c < n - 1; ++c) {
+        const float v = src[c];
+        pts[r * (n - 1) + c] = mode == 0 ? expf(v) : copysignf(expm1f(fabsf(v)), v);
+    }
+    conf[r] = 1.f + expf(src[n - 1]);
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh,
+                         int kw, int sh, int sw, int t0, int nt, int relu_in, void* stream) {
+    if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out)) {
+        fw_set_error("fw_im2col: C, ldx, ldo must be multiples of 8 and the bases 16-byte aligned"); return FW_E_BADARG; }
+    if (kt < 1 || kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1) || sh < 1 || sw < 1 || t0 < 0 || nt < 0 || t0 + nt > T) {
+        fw_set_error("fw_im2col: bad kernel / stride / frame window"); return FW_E_BADARG; }
+    const int Ho = (H + 2 * (kh / 2) - kh) / sh + 1, Wo = (W + 2 * (kw / 2) - kw) / sw + 1;
+    const int64_t total = (int64_t)nt * Ho * Wo * kt * kh * kw * (C / 8);
+    if (total <= 0) return 0;
+    if ((total + 255) / 256 > 0x7fffffffLL) { fw_set_error("fw_im2col: grid too large, chunk the frames"); return FW_E_BADARG; }
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, C / 8, T, H, W,
+                       Ho, Wo, kt, kh, kw, sh, sw, t0, total, relu_in);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_resize_bilinear(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int N, int h, int w, int H, int W,
+                                  int C, void* stream) {
+    if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out) || h < 1 || w < 1 || H < 1 || W < 1) {
+        fw_set_error("fw_resize_bilinear: C, ldx, ldo must be multiples of 8, bases 16-byte aligned, sizes positive"); return FW_E_BADARG; }
+    const int64_t total = (int64_t)N * H * W * (C / 8);
+    if (total <= 0) return 0;
+    if ((total + 255) / 256 > 0x7fffffffLL) { fw_set_error("fw_resize_bilinear: grid too large, chunk the frames"); return FW_E_BADARG; }
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, C / 8, h, w,
+                       H, W, sy, sx, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_chan_rmsnorm_silu(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int64_t rows, int C, int c_true,
+                                    const float* gamma, void* stream) {
+    if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out) || c_true <= 0 || c_true > C || !gamma) {
+        fw_set_error("fw_chan_rmsnorm_silu: bad arguments"); return FW_E_BADARG; }
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(chan_rmsnorm_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
+                       rows, C, sqrtf((float)c_true), gamma);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_depth_to_space(const uint16_t* y, int64_t ldy, uint16_t* out, int64_t ldo, int N, int h, int w, int k, int C,
+                                 void* stream) {
+    if (C <= 0 || (C % 8) || (ldy % 8) || (ldo % 8) || !aligned16(y) || !aligned16(out) || k < 1) {
+        fw_set_error("fw_depth_to_space: bad arguments"); return FW_E_BADARG; }
+    const int64_t total = (int64_t)N * h * k * w * k * (C / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, out, ldo, C / 8, h, w, k,
+                       total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_add_table(uint16_t* x, int64_t ldx, const float* table, int64_t rows, int hw, int C, void* stream) {
+    if (C <= 0 || (C % 8) || (ldx % 8) || !aligned16(x) || !aligned16(table) || hw <= 0 || (rows % hw)) {
+        fw_set_error("fw_add_table: C, ldx % 8, 16-byte bases and rows % hw == 0 required"); return FW_E_BADARG; }
+    const int64_t total = rows * (C / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(add_table_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, table, C / 8, hw, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_unfold_time2(const uint16_t* y, int64_t ldy, uint16_t* out, int64_t ldo, int n, int hw, int C, void* stream) {
+    if (C <= 0 || (C % 8) || (ldy % 8) || (ldo % 8) || !aligned16(y) || !aligned16(out)) {
+        fw_set_error("fw_unfold_time2: bad arguments"); return FW_E_BADARG; }
+    const int64_t total = (int64_t)2 * n * hw * (C / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(unfold_time2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, out, ldo, C / 8, hw, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_add_act(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, int relu, void* stream) {
+    if ((n % 8) || !aligned16(a) || !aligned16(out) || (b && !aligned16(b))) {
+        fw_set_error("fw_add_act: element count must be a multiple of 8 and the bases 16-byte aligned"); return FW_E_BADARG; }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_act_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 8, relu);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_adaln_rows(const float* x, const float* mod, float* out, int rows, int C, float eps, void* stream) {
+    if (!x || !mod || !out || C <= 0) { fw_set_error("fw_adaln_rows: bad arguments"); return FW_E_BADARG; }
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(adaln_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, mod, out, rows, C, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_head_activation(const float* y, int64_t rows, int n, int mode, float* pts, float* conf, void* stream) {
+    if (!y || !pts || n < 2 || mode < 0 || mode > 2 || (mode != 2 && !conf)) { fw_set_error("fw_head_activation: bad arguments"); return FW_E_BADARG; }
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(head_activation_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, y, rows, n, mode, pts, conf);
+    return (int)hipGetLastError();
+}

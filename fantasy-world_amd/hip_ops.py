@@ -23,6 +23,8 @@ SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
     "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_control_patchify", "fw_im2col3x3",
+    "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
+    "fw_add_act", "fw_adaln_rows", "fw_head_activation",
 ]
 
 _lib = None
@@ -60,12 +62,21 @@ def load_library(path: str = LIB_PATH):
         "fw_debug_attention_timestamps": [vp, i32],
         "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
+        "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+        "fw_resize_bilinear": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp],
+        "fw_chan_rmsnorm_silu": [vp, i64, vp, i64, i64, i32, i32, vp, vp],
+        "fw_depth_to_space": [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
+        "fw_add_table": [vp, i64, vp, i64, i32, i32, vp],
+        "fw_unfold_time2": [vp, i64, vp, i64, i32, i32, i32, vp],
+        "fw_add_act": [vp, vp, vp, i64, i32, vp],
+        "fw_adaln_rows": [vp, vp, vp, i32, i32, f32, vp],
+        "fw_head_activation": [vp, i64, i32, i32, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    if lib.fw_abi_version() != 2:
+    if lib.fw_abi_version() != 3:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -313,6 +324,92 @@ class HipOps:
         _check(self.lib.fw_im2col3x3(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), C, F, h, w, self._stream()),
                "fw_im2col3x3")
         return out
+
+    # ---- geometry heads: channels-last feature maps [frames*H*W, C] -------------------------------
+    def _bf16_rows(self, x):
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0, (x.dtype, x.shape)
+
+    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False):
+        """Gather of a convolution as GEMM (fw_im2col): [T*H*W, C] -> [nt*Ho*Wo, kt*kh*kw*C], tap-major columns."""
+        self._bf16_rows(x)
+        assert x.shape[0] == T * H * W
+        nt = T - t0 if nt is None else nt
+        C = x.shape[1]
+        Ho, Wo = (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1
+        out = torch.empty(nt * Ho * Wo, kt * kh * kw * C, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_im2col(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), C, T, H, W, kt, kh, kw, sh, sw,
+                                  t0, nt, int(relu_in), self._stream()), "fw_im2col")
+        return out
+
+    def resize_bilinear(self, x, N, h, w, H, W):
+        self._bf16_rows(x)
+        assert x.shape[0] == N * h * w
+        out = torch.empty(N * H * W, x.shape[1], dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_resize_bilinear(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), N, h, w, H, W,
+                                           x.shape[1], self._stream()), "fw_resize_bilinear")
+        return out
+
+    def chan_rmsnorm_silu(self, x, gamma, c_true):
+        self._bf16_rows(x)
+        assert gamma.dtype == torch.float32 and gamma.numel() == x.shape[1]
+        out = torch.empty_like(x)
+        _check(self.lib.fw_chan_rmsnorm_silu(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                                             int(c_true), gamma.data_ptr(), self._stream()), "fw_chan_rmsnorm_silu")
+        return out
+
+    def depth_to_space(self, y, N, h, w, k, C):
+        self._bf16_rows(y)
+        assert y.shape == (N * h * w, k * k * C)
+        out = torch.empty(N * h * k * w * k, C, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_depth_to_space(y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), N, h, w, k, C,
+                                          self._stream()), "fw_depth_to_space")
+        return out
+
+    def add_table(self, x, table):
+        self._bf16_rows(x)
+        assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1] == x.shape[1]
+        _check(self.lib.fw_add_table(x.data_ptr(), x.stride(0), table.data_ptr(), x.shape[0], table.shape[0], x.shape[1],
+                                     self._stream()), "fw_add_table")
+        return x
+
+    def unfold_time2(self, y, n, hw, C):
+        self._bf16_rows(y)
+        assert y.shape == (n * hw, 2 * C)
+        out = torch.empty(2 * n * hw, C, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_unfold_time2(y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0), n, hw, C, self._stream()),
+               "fw_unfold_time2")
+        return out
+
+    def add_act(self, a, b=None, relu=False):
+        assert a.dtype == torch.bfloat16 and a.is_contiguous() and (b is None or (b.shape == a.shape and b.is_contiguous()
+                                                                                  and b.dtype == torch.bfloat16))
+        out = torch.empty_like(a)
+        _check(self.lib.fw_add_act(a.data_ptr(), _ptr(b), out.data_ptr(), a.numel(), int(relu), self._stream()), "fw_add_act")
+        return out
+
+    def adaln_rows(self, x, mod):
+        assert x.dtype == torch.float32 and mod.dtype == torch.float32 and x.is_contiguous() and mod.is_contiguous()
+        rows, C = x.shape
+        assert mod.shape == (rows, 3 * C)
+        out = torch.empty_like(x)
+        _check(self.lib.fw_adaln_rows(x.data_ptr(), mod.data_ptr(), out.data_ptr(), rows, C, 1e-6, self._stream()),
+               "fw_adaln_rows")
+        return out
+
+    HEAD_MODES = {"exp": 0, "inv_log": 1, "pose": 2}
+
+    def head_activation(self, y, mode):
+        assert y.dtype == torch.float32 and y.dim() == 2 and y.is_contiguous()
+        rows, n = y.shape
+        if mode == "pose":
+            out = torch.empty_like(y)
+            _check(self.lib.fw_head_activation(y.data_ptr(), rows, n, 2, out.data_ptr(), None, self._stream()), "fw_head_activation")
+            return out
+        pts = torch.empty(rows, n - 1, dtype=torch.float32, device=self.device)
+        conf = torch.empty(rows, dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_head_activation(y.data_ptr(), rows, n, self.HEAD_MODES[mode], pts.data_ptr(), conf.data_ptr(),
+                                           self._stream()), "fw_head_activation")
+        return pts, conf
 
     def cast_act(self, x):
         assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1

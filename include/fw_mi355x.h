@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 2
+#define FW_ABI_VERSION 3
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -201,6 +201,54 @@ int fw_control_patchify(const void* in, int dtype, uint16_t* P, int64_t ldp, int
  * wan_video_camera_controller.py:64-76): x [F*Hh*Ww][C] bf16 (ldx) -> out [L][9*C] (ldo), column c*9 + ky*3 + kx.
  */
 int fw_im2col3x3(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int F, int Hh, int Ww, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * VGGT geometry heads (VGGT._head_predction, FantasyWorld/vggt/models/vggt.py:134-154): the pieces around
+ * fw_gemm_bf16.  Feature maps are channels-last matrices [frames*H*W][C] in bf16, C a multiple of 8, 16-byte aligned rows;
+ * a k x k (x k) convolution is fw_im2col followed by fw_gemm_bf16 with the weight flattened tap-major ([N][kt][kh][kw][C]).
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/*
+ * Gather for nn.Conv2d 3x3 (stride 1 or 2, padding 1: vggt/heads/dpt_head.py:82-87, 352-397, 412-428) and CausalConv3d
+ * (wan/modules/vae_modified.py:17-36; kernels (3,1,1) and (3,3,3)).  x [T*H*W][C] -> out rows (t - t0, yo, xo) for output
+ * frames t0..t0+nt-1, column ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][yo*sh + dy - kh/2][xo*sw + dx - kw/2][c], zero
+ * outside the volume (causal in time, 'same' in space).  relu_in applies ReLU to the gathered values.
+ */
+int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh, int kw,
+              int sh, int sw, int t0, int nt, int relu_in, void* stream);
+
+/* F.interpolate(mode="bilinear", align_corners=True) (custom_interpolate, vggt/heads/dpt_head.py:538-566):
+ * x [N*h*w][C] -> out [N*H*W][C]. */
+int fw_resize_bilinear(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int N, int h, int w, int H, int W, int C,
+                       void* stream);
+
+/* SiLU(RMS_norm(x)) over channels (ResidualBlock_Half, wan/modules/vae_modified.py:39-54, 201-203):
+ * out = silu(x / max(|x|_2, 1e-12) * sqrt(c_true) * gamma[c]); channels [c_true, C) are padding (zero in, zero out). */
+int fw_chan_rmsnorm_silu(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int64_t rows, int C, int c_true,
+                         const float* gamma, void* stream);
+
+/* nn.ConvTranspose2d with kernel = stride = k (vggt/heads/dpt_head.py:68-81) after its GEMM:
+ * y[(n, yy, xx)][(dy*k + dx)*C + c] -> out[(n, yy*k + dy, xx*k + dx)][c]. */
+int fw_depth_to_space(const uint16_t* y, int64_t ldy, uint16_t* out, int64_t ldo, int N, int h, int w, int k, int C, void* stream);
+
+/* x[(n, p)][c] += table[p][c] (fp32 [hw][C]): UV positional embedding (_apply_pos_embed, vggt/heads/dpt_head.py:262-283). */
+int fw_add_table(uint16_t* x, int64_t ldx, const float* table, int64_t rows, int hw, int C, void* stream);
+
+/* Resample 'upsample3d' (wan/modules/vae_modified.py:121-124): y[(i, p)][j*C + c] -> out[(2i + j, p)][c], j in {0, 1}. */
+int fw_unfold_time2(const uint16_t* y, int64_t ldy, uint16_t* out, int64_t ldo, int n, int hw, int C, void* stream);
+
+/* out = relu?(a + b) on contiguous bf16 tensors of n elements (b may be NULL): FeatureFusionBlock's skip sum, which the
+ * following ResidualConvUnit's in-place ReLU rewrites (vggt/heads/dpt_head.py:440, 517-522). */
+int fw_add_act(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, int relu, void* stream);
+
+/* CameraHead.trunk_fn modulation (vggt/heads/camera_head.py:124-128): out = gate * (LN(x) * (1 + scale) + shift) + x with
+ * mod[row] = shift | scale | gate ([rows][3C]), LayerNorm without affine, fp32. */
+int fw_adaln_rows(const float* x, const float* mod, float* out, int rows, int C, float eps, void* stream);
+
+/* activate_head / activate_pose (vggt/heads/head_act.py:11-33, 61-125) on y [rows][n] fp32:
+ * mode 0 "exp": pts[rows][n-1] = exp(.), conf = 1 + exp(y[:, n-1]); mode 1 "inv_log": pts = sign(v) expm1(|v|), same conf;
+ * mode 2 "pose": pts[rows][n] = y with ReLU on columns >= 7 (conf unused). */
+int fw_head_activation(const float* y, int64_t rows, int n, int mode, float* pts, float* conf, void* stream);
 
 #ifdef __cplusplus
 }

@@ -245,11 +245,11 @@ class TorchRefOps:
         """[n*hw, 2C] -> [2n*hw, C]: columns [0:C] are frame 2i, [C:2C] frame 2i+1 (vae_modified.py:121-124)."""
         return y.view(n, hw, 2, C).permute(0, 2, 1, 3).reshape(2 * n * hw, C).contiguous()
 
-    def add_act(self, a, b=None, relu=False, out_f32=False):
+    def add_act(self, a, b=None, relu=False):
         y = a.to(torch.float32) if b is None else a.to(torch.float32) + b.to(torch.float32)
         if relu:
             y = F.relu(y)
-        return y if out_f32 else self._r(y)
+        return self._r(y)
 
     def adaln_rows(self, x, mod):
         """gate * (LN(x) * (1 + scale) + shift) + x with per-row shift|scale|gate = mod [rows, 3C] (camera_head.py:124-128)."""
