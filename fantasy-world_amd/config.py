@@ -116,3 +116,9 @@ class HeadsConfig:
         """Reduced widths for CPU tests (same structure; the reference modules take these as constructor arguments)."""
         return HeadsConfig(dim_in=128, trunk_depth=2, cam_heads=2, features=64, out_channels=[64, 64, 128, 128],
                            layer_idx=[3, 2, 1, 0], dpt_patch=4)
+
+    @staticmethod
+    def e2e_small():
+        """Heads that hang on a reduced-depth fusion model (2 IRG layers, VGGT width 1024): true token width, narrow DPT."""
+        return HeadsConfig(dim_in=2048, trunk_depth=1, cam_heads=16, features=64, out_channels=[64, 64, 128, 128],
+                           layer_idx=[1, 0, 1, 0], dpt_patch=4)

@@ -57,13 +57,18 @@ class _Stage:
 class FusionEngine:
     """Holds the pre-packed weights of one fusion model on one device and runs joint_forward on it."""
 
-    def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None):
+    def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None, heads_cfg=None):
         """`get(name)` returns the reference parameter `name` (any dtype/device); tensors are packed block by block
         so a 14B model never needs a second full-precision copy.  `shard` is an optional
-        fantasy_world_amd.parallel.SequenceShard (one process per GPU, RCCL)."""
+        fantasy_world_amd.parallel.SequenceShard (one process per GPU, RCCL).  `heads_cfg` (config.HeadsConfig) enables the
+        geometry heads: joint_forward(return_prediction=True) then returns the reference's prediction dict
+        (vggt.py:134-154); their weights are packed on first use."""
         self.cfg = cfg
         self.ops = ops
         self.shard = shard
+        self.heads_cfg = heads_cfg
+        self._heads = None
+        self._get = get
         self._tables = {}
         self._plucker_zero_cache = None
         ops_ = ops
@@ -395,11 +400,11 @@ class FusionEngine:
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
                       plucker_context_lens=None, uncond=False, return_prediction=False, camera_token=None,
                       control_camera_latents_input=None, collect=None):
-        """Returns (noise_pred [1,16,F,H,W] in x.dtype, output_list or None).
+        """Returns (noise_pred [1,16,F,H,W] in x.dtype, prediction).
 
-        output_list (only when return_prediction): dict layer -> fp32 [1, S, P, 2*C] for the layers the geometry
-        heads read (dpt_head.py:44 -> 23,17,11,7 and camera_head.py:89 -> last); the heads themselves stay with the
-        caller (fantasy_world_amd.install wires them to the reference's vggt._head_predction).
+        prediction is None unless return_prediction.  With `heads_cfg` it is the reference's prediction dict (pose_enc,
+        depth, depth_conf, world_points, world_points_conf; vggt.py:134-154) computed by fantasy_world_amd.heads; without
+        it, the aggregator's output_list as a dict layer -> fp32 [1, S, P, 2*C] for the layers the heads read.
         `collect`: optional dict that receives intermediate tensors (tests).
         """
         cfg, ops, sh = self.cfg, self.ops, self.shard
@@ -469,7 +474,8 @@ class FusionEngine:
 
         need = set()
         if return_prediction:
-            need = {7, 11, 17, 23, cfg.n_irg - 1}
+            # the layers the geometry heads read: dpt_head.py:44 (23, 17, 11, 7) and camera_head.py:89 (the last one)
+            need = set(self.heads_cfg.layer_idx if self.heads_cfg is not None else (7, 11, 17, 23)) | {cfg.n_irg - 1}
         outputs = {}
         for i in range(cfg.n_irg):
             fb = self.frame[i]
@@ -506,8 +512,17 @@ class FusionEngine:
         if return_prediction:
             if sh is not None:
                 outputs = {k: sh.gather_frames(v) for k, v in outputs.items()}
-            return out, outputs
+            if self.heads_cfg is None:
+                return out, outputs
+            # once per generation; with a sequence shard every rank holds all frames here and computes the same dict
+            return out, self.geometry_heads().predict(outputs, F, h, w, patch_start_idx=cfg.n_special)
         return out, None
+
+    def geometry_heads(self):
+        if self._heads is None:
+            from .heads import GeometryHeads
+            self._heads = GeometryHeads(self.heads_cfg, self._get, self.ops)
+        return self._heads
 
     # ------------------------------------------------------------------------------------------------ helpers
     def _special_for(self, sh):

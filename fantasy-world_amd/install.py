@@ -8,14 +8,15 @@
 
 The replacement keeps the reference signature and return convention
 (FantasyWorld/fusion/model_wan21.py:104-116,217-224): (noise_pred[B,16,F,H,W] in x.dtype, prediction dict | None).
-The once-per-generation geometry heads stay the reference's own modules: on the last step the engine
-hands the aggregated tokens of layers 7/11/17/23 to vggt._head_predction (vggt/models/vggt.py:134-154).
+The once-per-generation geometry heads (vggt._head_predction, vggt/models/vggt.py:134-154) run on the same
+engine (fantasy_world_amd.heads) when the model carries all three of them; a VGGT with a head switched off keeps the
+reference's own head modules on the aggregated tokens the engine returns.
 """
 import types
 
 import torch
 
-from .config import FWConfig
+from .config import FWConfig, HeadsConfig
 from .engine import FusionEngine
 
 
@@ -43,6 +44,20 @@ def config_from_model(model) -> FWConfig:
     return cfg
 
 
+def heads_config_from_model(vggt):
+    """HeadsConfig read off the live head modules (vggt/models/vggt.py:31-34), or None when one of them is disabled."""
+    cam, dep, pts = (getattr(vggt, n, None) for n in ("camera_head", "depth_head", "point_head"))
+    if cam is None or dep is None or pts is None:
+        return None
+    dim = cam.token_norm.normalized_shape[0]
+    return HeadsConfig(
+        dim_in=dim, trunk_depth=len(cam.trunk), cam_heads=cam.trunk[0].attn.num_heads,
+        cam_mlp_ratio=cam.trunk[0].mlp.fc1.out_features // dim, features=dep.scratch.layer1_rn.out_channels,
+        out_channels=[p.out_channels for p in dep.projects], layer_idx=list(dep.intermediate_layer_idx),
+        dpt_patch=dep.patch_size, depth_out=dep.scratch.output_conv2[2].out_channels,
+        point_out=pts.scratch.output_conv2[2].out_channels)
+
+
 def install(model, ops=None, device=None):
     """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
     tests may inject another op set to exercise this boundary on CPU."""
@@ -51,7 +66,7 @@ def install(model, ops=None, device=None):
         ops = HipOps(device or "cuda")
     cfg = config_from_model(model)
     params = dict(model.named_parameters())
-    engine = FusionEngine(cfg, params.__getitem__, ops)
+    engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt))
 
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
                       camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,
@@ -63,6 +78,8 @@ def install(model, ops=None, device=None):
                                             control_camera_latents_input=control_camera_latents_input)
         if not return_prediction:
             return out, None
+        if engine.heads_cfg is not None:
+            return out, outputs                      # the prediction dict, computed by fantasy_world_amd.heads
         n = cfg.n_irg
         output_list = [outputs.get(i) for i in range(n)]
         f, h, w = x.shape[2], x.shape[3] // 2, x.shape[4] // 2

@@ -243,7 +243,8 @@ def control_adapter(ctl, W, pre):
 def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
                   plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None):
     """W: name -> fp32 tensor (reference parameter names). Returns noise_pred [1,16,F,H,W] (fp32).
-    The geometry heads (return_prediction) are not part of the oracle: they stay the reference's modules."""
+    Pass collect={"output_list": {}} to receive the aggregator's output_list (layer -> [f, P, 2C]), the input of the geometry
+    heads (oracle/fw_heads_oracle.py restates VGGT._head_predction on it)."""
     pd = "pipe.dit."
     f = x.shape[2]
     # A1 (wan_video_dit.py:393-399)
@@ -304,6 +305,7 @@ def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluck
         fp = f"vggt.aggregator.frame_blocks.{i}."
         tokens, e_f = vggt_block_partial(tokens, pos, e0, W, fp, cfg)         # [f, P, C], frame attention
         tokens = vggt_block_remaining(tokens, e_f, W, fp, cfg)
+        frame_out = tokens
         p = cfg.dit_prefix(cfg.start_index + i)
         gp = cfg.global_prefix(i)
         adapter = cfg.has_adapter(cfg.start_index + i)
@@ -316,6 +318,9 @@ def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluck
         x = dit_block_remaining(x, mods, W, p, cfg)
         tg = vggt_block_remaining(tg, e_g, W, gp, cfg)
         tokens = tg.reshape(f, P, -1)
+        if collect is not None and "output_list" in collect:
+            # model_wan21.py:208-212: frame | global intermediates of every layer, concatenated on channels -> [f, P, 2C]
+            collect["output_list"][i] = torch.cat([frame_out, tokens], dim=-1)
     if collect is not None:
         collect["x_final"] = x[0].clone()
         collect["tokens_final"] = tokens.reshape(f * P, -1).clone()

@@ -106,6 +106,42 @@ def main():
         print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+def main_pred(only):
+    """End to end: the REAL reference's joint_forward(return_prediction=True) on a reduced-depth fusion model whose VGGT
+    carries narrow geometry heads (HeadsConfig.e2e_small()) -> noise_pred and the prediction dict."""
+    name = "wan21_pred_l3_f2_8x12"
+    if only and name not in only:
+        return
+    ckw, (f, h2, w2), ts, tl = dict(num_layers=3, start_index=1), (2, 8, 12), 125.0, 512
+    cfg, hc = fwc.plumbing(**ckw), fwc.HeadsConfig.e2e_small()
+    W = synth.make_weights(cfg)
+    W.update(synth.make_heads_weights(hc))
+    ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=ts, text_len=tl)
+    model = ref_harness.build_reference_wan21(cfg, weights=W, heads_cfg=hc)
+    assert not model._fw_unused, model._fw_unused[:5]
+    t0 = time.time()
+    with torch.no_grad():
+        out, pred = model.joint_forward(
+            ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
+            use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+            plucker_context_lens=ins["plucker_context_lens"], uncond=False, return_prediction=True)
+    print(f"[{name}] reference joint_forward(return_prediction=True) {time.time()-t0:.1f}s")
+    col = {"output_list": {}}
+    orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
+                                  ins["plucker_fea"], ins["plucker_context_lens"], collect=col)
+    opred = fw_heads_oracle.head_prediction(W, col["output_list"], hc, f, h2 // 2, w2 // 2)
+    print(f"   oracle vs reference  noise_pred         rel-L2 = {rel(orc, out):.3e}")
+    for k in pred:
+        print(f"   oracle vs reference  {k:18s} rel-L2 = {rel(opred[k], pred[k]):.3e}   shape {tuple(pred[k].shape)}")
+    golden = {k: v.to(torch.float32).contiguous() for k, v in pred.items()}
+    golden["noise_pred"] = out.to(torch.float32).contiguous()
+    golden["meta"] = dict(cfg=ckw, grid=(f, h2, w2), timestep=ts, text_len=tl, uncond=False, seed_weights=0, seed_inputs=1,
+                          torch=torch.__version__, flavour="wan21", heads="e2e_small")
+    path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+    torch.save(golden, path)
+    print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def main_heads(only):
     for name, (S, ph, pw) in HEAD_CASES.items():
         if only and name not in only:
@@ -135,6 +171,10 @@ def _cold(name):
 
 
 if __name__ == "__main__":
-    if not sys.argv[1:] or any(not a.startswith("heads") for a in sys.argv[1:]):
+    args = sys.argv[1:]
+    if not args or any(a in CASES for a in args):
         main()
-    main_heads([a for a in sys.argv[1:] if a.startswith("heads")] if sys.argv[1:] else [])
+    if not args or any(a.startswith("heads") for a in args):
+        main_heads([a for a in args if a.startswith("heads")])
+    if not args or any("_pred_" in a for a in args):
+        main_pred([a for a in args if "_pred_" in a])

@@ -116,7 +116,20 @@ class _FakePipe(nn.Module):
         pass
 
 
-def build_reference_wan21(cfg, weights=None):
+def _swap_heads(vggt, hc):
+    """Replace the (full-width) geometry heads of a reference VGGT by ones built from `hc` (constructor arguments only)."""
+    from FantasyWorld.vggt.heads.camera_head import CameraHead
+    from FantasyWorld.vggt.heads.dpt_head import DPTHead_3D_Causal
+    vggt.camera_head = CameraHead(dim_in=hc.dim_in, trunk_depth=hc.trunk_depth, num_heads=hc.cam_heads,
+                                  mlp_ratio=hc.cam_mlp_ratio)
+    kw = dict(dim_in=hc.dim_in, patch_size=hc.dpt_patch, features=hc.features, out_channels=list(hc.out_channels),
+              intermediate_layer_idx=list(hc.layer_idx))
+    vggt.depth_head = DPTHead_3D_Causal(output_dim=hc.depth_out, activation="exp", conf_activation="expp1", **kw)
+    vggt.point_head = DPTHead_3D_Causal(output_dim=hc.point_out, activation="inv_log", conf_activation="expp1", **kw)
+    vggt.track_head = None
+
+
+def build_reference_wan21(cfg, weights=None, heads_cfg=None):
     """Build the reference FantasyWorldFusionModel (Wan2.1 flavour) for `cfg` (fantasy_world_amd.config.FWConfig).
 
     Mirrors FantasyWorld/fusion/model_wan21.py:24-102 without touching checkpoints or "cuda".
@@ -138,6 +151,8 @@ def build_reference_wan21(cfg, weights=None):
                        num_heads=cfg.num_heads, num_layers=cfg.num_layers, has_image_input=cfg.has_image_input)
         vggt = VGGT(enable_camera=True, enable_depth=True, enable_point=True, enable_track=False,
                     DPT_patch_size=16)
+        if heads_cfg is not None:
+            _swap_heads(vggt, heads_cfg)
     if weights is not None:
         # RoPE tables are plain attributes (not buffers): rebuild them off the meta device
         dit.freqs = precompute_freqs_cis_3d(cfg.dim // cfg.num_heads)
@@ -300,18 +315,10 @@ def build_reference_heads(hc, weights):
     reference's parameter names (prefix "vggt.")."""
     install_stubs()
     from FantasyWorld.vggt.models.vggt import VGGT
-    from FantasyWorld.vggt.heads.camera_head import CameraHead
-    from FantasyWorld.vggt.heads.dpt_head import DPTHead_3D_Causal
 
     vggt = VGGT.__new__(VGGT)
     nn.Module.__init__(vggt)
-    vggt.camera_head = CameraHead(dim_in=hc.dim_in, trunk_depth=hc.trunk_depth, num_heads=hc.cam_heads,
-                                  mlp_ratio=hc.cam_mlp_ratio)
-    kw = dict(dim_in=hc.dim_in, patch_size=hc.dpt_patch, features=hc.features, out_channels=list(hc.out_channels),
-              intermediate_layer_idx=list(hc.layer_idx))
-    vggt.depth_head = DPTHead_3D_Causal(output_dim=hc.depth_out, activation="exp", conf_activation="expp1", **kw)
-    vggt.point_head = DPTHead_3D_Causal(output_dim=hc.point_out, activation="inv_log", conf_activation="expp1", **kw)
-    vggt.track_head = None
+    _swap_heads(vggt, hc)
     holder = nn.Module()
     holder.vggt = vggt
     missing, unused = load_named_weights(holder, weights)

@@ -89,3 +89,19 @@ def heads_case(request):
 
 
 PRED_KEYS = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")
+
+
+class PredCase(Case):
+    """End-to-end case with return_prediction=True: the fusion model of a Case plus narrow geometry heads
+    (HeadsConfig.e2e_small()); golden = noise_pred and the prediction dict of the REAL reference."""
+
+    def __init__(self, name):
+        from fantasy_world_amd import config as fwc, synth
+        super().__init__(name)
+        self.hc = fwc.HeadsConfig.e2e_small()
+        self.weights.update(synth.make_heads_weights(self.hc, seed=self.golden["meta"]["seed_weights"]))
+
+
+@pytest.fixture(scope="session")
+def case_pred():
+    return PredCase("wan21_pred_l3_f2_8x12")

@@ -67,3 +67,20 @@ def test_wan22_control_features_are_cached_per_tensor(case_w22):
     d, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
     assert torch.equal(c, d)
     kw["control_camera_latents_input"].mul_(0.5)
+
+
+def test_engine_return_prediction_matches_reference_golden(case_pred):
+    """joint_forward(return_prediction=True) with heads_cfg returns the reference's prediction dict (M21:217-224)."""
+    from conftest import PRED_KEYS, forward_kwargs
+    c, ins = case_pred, case_pred.inputs
+    eng = FusionEngine(c.cfg, c.weights.__getitem__, TorchRefOps(), heads_cfg=c.hc)
+    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], return_prediction=True, **forward_kwargs(c))
+    assert rel_l2(out, c.golden["noise_pred"]) < 2e-5
+    assert set(pred.keys()) == set(PRED_KEYS)
+    for k in PRED_KEYS:
+        assert pred[k].shape == c.golden[k].shape
+        assert rel_l2(pred[k], c.golden[k]) < 5e-5, k
+    # without heads_cfg the aggregated tokens come back instead (the layers the heads would read)
+    eng2 = FusionEngine(c.cfg, c.weights.__getitem__, TorchRefOps())
+    _, outputs = eng2.joint_forward(ins["x"], ins["timestep"], ins["context"], return_prediction=True, **forward_kwargs(c))
+    assert all(v.shape[-1] == 2 * c.cfg.vggt_dim for v in outputs.values()) and (c.cfg.n_irg - 1) in outputs

@@ -50,3 +50,18 @@ def test_heads_oracle_matches_live_reference():
     pred = fw_heads_oracle.head_prediction(W, ol, hc, S, ph, pw)
     for k in PRED_KEYS:
         assert rel_l2(pred[k], ref[k]) < 5e-6, k
+
+
+def test_oracle_chain_matches_reference_prediction_golden(case_pred):
+    """joint_forward's output_list fed to the heads oracle == the reference's joint_forward(return_prediction=True)."""
+    from conftest import PRED_KEYS
+    from oracle import fw_heads_oracle
+    c, ins = case_pred, case_pred.inputs
+    col = {"output_list": {}}
+    out = fw_oracle.joint_forward(c.weights, c.cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
+                                  ins["plucker_fea"], ins["plucker_context_lens"], collect=col)
+    assert rel_l2(out, c.golden["noise_pred"]) < 5e-6
+    f, h2, w2 = c.grid
+    pred = fw_heads_oracle.head_prediction(c.weights, col["output_list"], c.hc, f, h2 // 2, w2 // 2)
+    for k in PRED_KEYS:
+        assert rel_l2(pred[k], c.golden[k]) < 1e-5, k
