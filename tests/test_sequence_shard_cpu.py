@@ -26,12 +26,20 @@ def _cfg():
     return fwc.plumbing(num_layers=2, start_index=1, ffn_dim=256)
 
 
+def _hc():
+    """Narrow geometry heads reading the single IRG layer of _cfg() (return_prediction under a sequence shard)."""
+    import dataclasses
+    from fantasy_world_amd import config as fwc
+    return dataclasses.replace(fwc.HeadsConfig.e2e_small(), layer_idx=[0, 0, 0, 0])
+
+
 @pytest.fixture(scope="module")
 def shared_weights(tmp_path_factory):
     """Synthetic weights are generated ONCE (they are ~1 B parameters even at depth 2: the reference hard-codes the widths)
     and handed to the spawned ranks through a file that every worker memory-maps."""
     from fantasy_world_amd import synth
     W = synth.make_weights(_cfg())
+    W.update(synth.make_heads_weights(_hc()))
     path = str(tmp_path_factory.mktemp("w") / "weights.pt")
     torch.save(dict(W), path)
     return W, path
@@ -54,10 +62,11 @@ def _worker(rank, world, port, grid, outdir, wpath):
     cfg = _cfg()
     W = _load_weights(wpath)
     ins = synth.make_inputs(cfg, *grid, seed=3)
-    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(), shard=SequenceShard(rank, world))
-    out, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
-                               plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"])
-    torch.save(out, os.path.join(outdir, f"out_{rank}.pt"))
+    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(), shard=SequenceShard(rank, world), heads_cfg=_hc())
+    out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
+                                  plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"],
+                                  return_prediction=True)
+    torch.save((out, pred), os.path.join(outdir, f"out_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,22 +74,27 @@ def _worker(rank, world, port, grid, outdir, wpath):
 @pytest.mark.parametrize("world,grid", [(3, (4, 4, 12))])
 def test_sequence_shard_matches_single_process(world, grid, tmp_path, shared_weights):
     """world 3: 40 and 16 heads do not divide -> K/V all-gather fallback, uneven frame split (2,1,1); the head-exchange path
-    (world 2 inside a CFG group) is covered by test_cfg_parallel_denoise_step_matches_single_process."""
+    (world 2 inside a CFG group) is covered by test_cfg_parallel_denoise_step_matches_single_process.  Run as the LAST
+    sampling step (return_prediction=True): the geometry heads see the gathered frames on every rank."""
     from fantasy_world_amd import synth
     from fantasy_world_amd.engine import FusionEngine
     from oracle.ref_ops import TorchRefOps
     cfg = _cfg()
     W, wpath = shared_weights
     ins = synth.make_inputs(cfg, *grid, seed=3)
-    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps())
-    want, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
-                                plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"])
+    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(), heads_cfg=_hc())
+    want, wpred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
+                                    plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"],
+                                    return_prediction=True)
     del eng
     mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path), wpath), nprocs=world, join=True)
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
     for r in range(world):
-        got = torch.load(os.path.join(str(tmp_path), f"out_{r}.pt"))
-        err = ((got.double() - want.double()).norm() / want.double().norm()).item()
-        assert err < 1e-5, (r, err)
+        got, pred = torch.load(os.path.join(str(tmp_path), f"out_{r}.pt"))
+        assert rel(got, want) < 1e-5, (r, rel(got, want))
+        # last step: the frame-sharded output_list is gathered and every rank computes the same prediction dict
+        for k, v in wpred.items():
+            assert pred[k].shape == v.shape and rel(pred[k], v) < 2e-5, (r, k, rel(pred[k], v))
 
 
 def test_split_counts():
