@@ -106,3 +106,34 @@ def uninstall(model):
         model.joint_forward = model._fw_reference_joint_forward
         del model._fw_reference_joint_forward
         del model._fw_engine
+
+
+def install_flash_attention(modules, ops=None, device=None, name="flash_attention"):
+    """Boundary B3: rebind the reference's op-level hook
+    `flash_attention(q, k, v, num_heads, compatibility_mode=False)` (diffsynth_wan21/models/wan_video_dit.py:28-66, same in
+    diffsynth_wan22) in the given reference modules, so an otherwise-reference forward runs its attention through
+    fw_attention_bf16.  q/k/v are [b, s, heads*hd] tensors; the result has q's shape and dtype.  Returns an `undo()` callable.
+
+        import FantasyWorld.diffsynth_wan21.models.wan_video_dit as dit
+        undo = install_flash_attention([dit])
+    """
+    if ops is None:
+        from .hip_ops import HipOps
+        ops = HipOps(device or "cuda")
+
+    def flash_attention(q, k, v, num_heads, compatibility_mode=False):
+        b, lq, d = q.shape
+        lk = k.shape[1]
+        hd = d // num_heads
+        to2 = lambda t, n: ops.to_act(t.reshape(b * n, d))
+        out = ops.attention(to2(q, lq), to2(k, lk), to2(v, lk), num_heads, hd, batch=b)
+        return out.view(b, lq, d).to(q.dtype)
+
+    saved = [(m, getattr(m, name)) for m in modules]
+    for m, _ in saved:
+        setattr(m, name, flash_attention)
+
+    def undo():
+        for m, f in saved:
+            setattr(m, name, f)
+    return undo

@@ -78,3 +78,34 @@ def test_install_returns_prediction_dict_on_last_step(case_pred):
     assert rel_l2(got, want) < 2e-5
     for k in PRED_KEYS:
         assert pred[k].shape == wpred[k].shape and rel_l2(pred[k], wpred[k]) < 5e-5, k
+
+
+def test_flash_attention_hook_b3():
+    """Boundary B3: the reference's module-level flash_attention hook rebound to the engine's attention op; the reference's
+    own DiTBlock then runs unchanged on top of it (SelfAttention -> AttentionModule -> flash_attention, DIT21:149-182)."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install_flash_attention
+    ref_harness.install_stubs()
+    import FantasyWorld.diffsynth_wan21.models.wan_video_dit as dit
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(2, n, 4 * 64, generator=g) for n in (37, 50, 50))
+    want = dit.flash_attention(q, k, v, 4)
+    calls = []
+    ops = TorchRefOps()
+    orig_attention = ops.attention
+    ops.attention = lambda *a, **kw: (calls.append(1), orig_attention(*a, **kw))[1]
+    undo = install_flash_attention([dit], ops=ops)
+    try:
+        got = dit.flash_attention(q, k, v, 4)
+        assert got.shape == want.shape and got.dtype == want.dtype and rel_l2(got, want) < 1e-5
+        blk = dit.SelfAttention(256, 4).eval()
+        x = torch.randn(1, 24, 256, generator=g)
+        freqs = torch.polar(torch.ones(24, 1, 32, dtype=torch.float64), torch.zeros(24, 1, 32, dtype=torch.float64))
+        n0 = len(calls)
+        with torch.no_grad():
+            y = blk(x, freqs)
+        assert len(calls) == n0 + 1 and y.shape == x.shape       # the reference module went through the hook
+    finally:
+        undo()
+    assert dit.flash_attention(q, k, v, 4).equal(want)

@@ -145,3 +145,61 @@ def test_hip_joint_forward_return_prediction(case_pred):
         assert pred[k].shape == c.golden[k].shape and pred[k].dtype == torch.float32
         assert torch.isfinite(pred[k]).all()
         assert errs[k] < PRED_TOL, (k, errs[k])
+
+
+def test_hip_sequence_shard_over_rccl_single_rank_group(case_l3):
+    """The multi-GPU code path on the hardware that is available to a test: a ONE-rank RCCL process group.  Every collective
+    of the sequence shard (all_to_all_single with split sizes, all_gather_into_tensor, async work handles waited on the compute
+    stream) runs through RCCL on device tensors in bf16 / fp32 and degenerates to a copy, so the sharded engine must
+    reproduce the unsharded one bit for bit.  (World sizes 2-4 are covered on CPU over gloo, tests/test_sequence_shard_cpu.py.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    from fantasy_world_amd.parallel import SequenceShard
+    case = case_l3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    created = False
+    if not dist.is_initialized():
+        try:
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", rank=0, world_size=1)
+            created = True
+        except Exception as e:                                   # no usable RCCL transport on this box
+            pytest.skip(f"RCCL process group unavailable: {e}")
+    try:
+        ops = HipOps("cuda:0")
+        ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
+        kw = forward_kwargs(case, "cuda")
+        want, _ = FusionEngine(case.cfg, case.weights.__getitem__, ops).joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+        eng = FusionEngine(case.cfg, case.weights.__getitem__, ops, shard=SequenceShard(0, 1))
+        got, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_flash_attention_hook_on_hip():
+    """Boundary B3 on the GPU: the rebound `flash_attention(q, k, v, num_heads)` hook ([b, s, heads*hd] tensors, bf16 as in
+    the inference scripts) against softmax(QK^T/sqrt(hd))V in fp32."""
+    import types
+    from fantasy_world_amd import install_flash_attention
+    mod = types.SimpleNamespace(flash_attention=None)
+    undo = install_flash_attention([mod], device="cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    b, heads, hd, lq, lk = 2, 5, 128, 300, 333
+    q, k, v = (torch.randn(b, n, heads * hd, device="cuda", generator=g).bfloat16() for n in (lq, lk, lk))
+    out = mod.flash_attention(q, k, v, heads)
+    assert out.shape == q.shape and out.dtype == q.dtype
+    qh, kh, vh = (t.float().view(b, -1, heads, hd).transpose(1, 2) for t in (q, k, v))
+    want = torch.softmax(qh @ kh.transpose(-1, -2) / hd ** 0.5, dim=-1) @ vh
+    assert rel_l2(out.float(), want.transpose(1, 2).reshape(b, lq, heads * hd)) < 4e-3
+    undo()
+    assert mod.flash_attention is None
