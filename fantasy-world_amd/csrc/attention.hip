@@ -1657,7 +1657,10 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
-    const int var = fw_get_option(FW_OPT_ATTN_VAR);     // 0 = first kernel; 16 + bits = ping-pong kernel (bit 0 prio, bit 1 deferred rescale)
+    int var = fw_get_option(FW_OPT_ATTN_VAR);           // 0 = first kernel; 16 + bits = ping-pong kernel (bit 0 prio, bit 1 deferred rescale)
+    // 192 = per-head-dim choice among the pre-scaled kernels (microbench, profiles/r01/attention_sp_ablation.txt): the
+    // single-stream kernel for hd 128 and hd 64, the two-segment ping-pong for hd 96
+    if (var == 192) var = head_dim == 96 ? 64 : 129;
     if (prescaled && var >= 128) {
         // single-stream software pipeline on half tiles; bit 0: pinned issue order, bit 1: one 64-row wave per SIMD
 #define FW_ATTN_SP(HDV, V) \

@@ -63,9 +63,13 @@ int fw_abi_version(void);
 #define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 3 = 128-B-row ping-pong with quarter-slab DMA (default), 1 = 5-deep half-slab ring,
                                   2 = four-wave 128x128 wave tile, 0 = first 2-stage staggered kernel (A/B baselines) */
 #define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: schedule variant bits of the selected 256x256 kernel (default 1 = s_setprio around MFMA bursts) */
-#define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 64 (default) = two-segment ping-pong kernels (log2-domain fast path when
-                                  FW_ATTN_Q_PRESCALED, else the generic two-segment kernel); 32+bits / 16+bits / 0 = earlier
-                                  schedules kept as A/B baselines; 66 = timing build (fw_debug_attention_timestamps) */
+#define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
+                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): 129 for hd 128 / 64, 64 for hd 96;
+                                   calls without the flag use the 2-segment kernel.  64 = two-segment ping-pong kernels, +1 K/Q
+                                   fragments by LDS-DMA; 128 + bits = single-stream half-tile pipeline (bit 0 pinned issue order,
+                                   bit 1 one 64-row wave per SIMD); 256 + bits = timing ablations of that kernel (wrong
+                                   results by construction, tools/microbench.py only); 32 + bits = 2-segment generic;
+                                   16 + bits = 4-segment ping-pong; 0 = the first kernel */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
 

@@ -11,5 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   for db in $(find $O/pmc_$c -name '*.db'); do python $R/tools/rocpd_summary.py $db --top 30 > $O/pmc_${c}_summary.txt 2>&1; done
   rm -rf $O/pmc_$c
 done
-grep -E "attention_pp3|gemm_bf16_pp|layernorm|qk_prep" $O/pmc_FETCH_SIZE_summary.txt | grep -E "FETCH|WRITE" | head -40
-grep -E "attention_pp3|gemm_bf16_pp|layernorm|qk_prep" $O/pmc_WRITE_SIZE_summary.txt | grep -E "FETCH|WRITE" | head -40
+grep -E "attention_sp|attention_pp3|gemm_bf16_pp|layernorm|qk_prep" $O/pmc_FETCH_SIZE_summary.txt | grep -E "FETCH|WRITE" | head -40
+grep -E "attention_sp|attention_pp3|gemm_bf16_pp|layernorm|qk_prep" $O/pmc_WRITE_SIZE_summary.txt | grep -E "FETCH|WRITE" | head -40

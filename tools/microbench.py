@@ -44,7 +44,7 @@ def main():
     rb = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
 
     gvars = [tuple(int(a) for a in v.split(":")) for v in args.gemm_variants.split(",") if v] or [(3, 1)]
-    avars = [int(v) for v in args.attn_variants.split(",") if v] or [64]
+    avars = [int(v) for v in args.attn_variants.split(",") if v] or [192]
     if args.only in ("", "gemm"):
       for (gk, gv) in gvars:
         ops.set_option("gemm_kernel", gk)
@@ -93,7 +93,7 @@ def main():
             gb = 2.0 * v.numel() * 2 / ms / 1e6
             print(f"     v_transpose {tag:14s} {ms:8.3f} ms  {gb:7.1f} GB/s", flush=True)
             del q, k, v, vp, out
-      ops.set_option("attn_var", 64)
+      ops.set_option("attn_var", 192)
     if args.only in ("", "glue"):
         x = torch.randn(L, 5120, device=dev)
         sc = torch.randn(5120, device=dev)
