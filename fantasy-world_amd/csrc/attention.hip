@@ -1194,6 +1194,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     // 4 = no exp, 8 = no fragment reads in the loop, 16 = no tile DMA and no barrier, 32 = no PV MFMAs
     constexpr bool AB_NOEXP = (VAR & 4) != 0, AB_NODS = (VAR & 8) != 0, AB_NODMA = (VAR & 16) != 0;
     constexpr bool AB_NOPV = (VAR & 32) != 0, AB_NOQK = false;
+    constexpr bool PAIR = (VAR & 128) != 0;   // one barrier per TWO 64-key tiles (FW_ATTN_VAR 160 + bits)
     constexpr int NS = (VAR & 2) ? 2 : 1;     // 32-row sub-blocks per wave: 2 = one wave per SIMD owning 64 query rows
     constexpr int NW = 8 / NS;                // waves per work-group (256 query rows either way)
     constexpr int NP = 16 / NW;               // 1 KiB K pieces / Vt pieces each wave requests per tile
@@ -1481,10 +1482,40 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
 
     // the shift splat was just written by VALU and the first asm MFMA reads it as srcC: that hazard is ours to cover
     if (NS == 2) asm volatile("s_nop 7" ::: "memory");
-    if (nt > 1) {
-        for (int t = 0; t < nt - 1; ++t) tile(t, F_{});
+    if (PAIR) {
+        // Two tiles per barrier.  Tile t reads K(t+1) and Vt(t) from LDS, so a pair (t, t+1) needs K(t+1), K(t+2), Vt(t),
+        // Vt(t+1) landed at its entry and leaves K(<= t), Vt(< t) dead: K(t+3), K(t+4), Vt(t+2), Vt(t+3) are requested at the
+        // entry of the pair (their ring slots hold K(t-1), K(t), Vt(t-2), Vt(t-1)) and awaited in full at its end -- one
+        // pair time (~3 us) of prefetch.  The extra barrier keeps the first request for K(4) off slot 0 until every wave
+        // has taken its K(0) fragments.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FW_ABARRIER();
+        int t = 0;
+        for (; t + 2 < nt; t += 2) {
+            issue_k(min(t + 3, nt - 1), t + 3);
+            issue_k(min(t + 4, nt - 1), t + 4);
+            issue_v(min(t + 2, nt - 1), t + 2);
+            issue_v(min(t + 3, nt - 1), t + 3);
+            half(sA, sB, t, H0{}, T_{}, T_{}, F_{});
+            half(sB, sA, t, H1{}, T_{}, T_{}, F_{});
+            half(sA, sB, t + 1, H0{}, T_{}, T_{}, F_{});
+            half(sB, sA, t + 1, H1{}, T_{}, T_{}, F_{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fw_await_vm<0>();
+            FW_ABARRIER();
+        }
+        if (t + 1 < nt) {                     // a non-last tile whose data the last pair already brought in
+            half(sA, sB, t, H0{}, T_{}, T_{}, F_{});
+            half(sB, sA, t, H1{}, T_{}, T_{}, F_{});
+            ++t;
+        }
+        tile(t, T_{});
+    } else {
+        if (nt > 1) {
+            for (int t = 0; t < nt - 1; ++t) tile(t, F_{});
+        }
+        tile(nt - 1, T_{});
     }
-    tile(nt - 1, T_{});
     if (NS == 2) fw_mfma_drain();
 
     if (__any(bad)) {
@@ -1676,6 +1707,10 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
                 case 32: FW_ATTN_SP(128, 3 + 32); break;
                 default: FW_ATTN_SP(128, 3); break;
             }
+            return (int)hipGetLastError();
+        }
+        if (var >= 160 && var < 192) {            // two tiles per barrier
+            if (var & 2) FW_ATTN_SP_HD(128 + 3); else FW_ATTN_SP_HD(128 + 1);
             return (int)hipGetLastError();
         }
         switch (var & 3) {

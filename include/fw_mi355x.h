@@ -67,7 +67,7 @@ int fw_abi_version(void);
                                    already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): 129 for hd 128 / 64, 64 for hd 96;
                                    calls without the flag use the 2-segment kernel.  64 = two-segment ping-pong kernels, +1 K/Q
                                    fragments by LDS-DMA; 128 + bits = single-stream half-tile pipeline (bit 0 pinned issue order,
-                                   bit 1 one 64-row wave per SIMD); 256 + bits = timing ablations of that kernel (wrong
+                                   bit 1 one 64-row wave per SIMD), 160 + those bits = same with two tiles per barrier; 256 + bits = timing ablations of that kernel (wrong
                                    results by construction, tools/microbench.py only); 32 + bits = 2-segment generic;
                                    16 + bits = 4-segment ping-pong; 0 = the first kernel */
 #define FW_OPT_COUNT       4

@@ -157,9 +157,9 @@ def test_gemv_f32(ops, ref):
 DEFAULT_ATTN_VAR = 192
 
 
-@pytest.fixture(params=[0, 18, 34, 64, 65, 128, 129, 131, 192],
+@pytest.fixture(params=[0, 18, 34, 64, 65, 128, 129, 131, 161, 163, 192],
                 ids=["attn_v0", "attn_pp4_defer", "attn_pp2", "attn_pp3", "attn_pp3_dmaqk", "attn_sp", "attn_sp_pinned",
-                     "attn_sp_w4", "attn_default"])
+                     "attn_sp_w4", "attn_sp_pair", "attn_sp_w4_pair", "attn_default"])
 def attn_variant(ops, request):
     """Every attention test runs on the first kernel (0), on the 4- and 2-segment ping-pong kernels, and on the fast
     log2-domain kernel (64+), which is selected when q carries the softmax scale (q_prescaled=True)."""
