@@ -45,3 +45,18 @@ def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cf
         neg, _ = engine.joint_forward(latents, t, ctx_neg, **cond)
     noise_pred = neg + cfg_scale * (pos - neg)
     return scheduler.step(noise_pred, step_id, latents), pred
+
+
+def select_expert(scheduler, step_id, engine_high, engine_low, timestep_boundary):
+    """Wan2.2 dual-expert rule (inference_wan22.py:229-240): the high-noise expert while the step's timestep is above the
+    boundary (compared on the host, like the reference's `t.item()`), the low-noise expert afterwards.  Both engines stay
+    resident (2 x 36 GB of packed weights in 288 GB of HBM), so switching costs nothing."""
+    return engine_high if float(scheduler.timesteps[step_id]) > float(timestep_boundary) else engine_low
+
+
+def denoise_step_dual(engine_high, engine_low, timestep_boundary, scheduler, step_id, latents, ctx_pos, ctx_neg, cond,
+                      cfg_scale=5.0, return_prediction=False, topo=None):
+    """One step of `generate_video_with_dual_models` (inference_wan22.py:227-277): pick the expert, then an ordinary step."""
+    engine = select_expert(scheduler, step_id, engine_high, engine_low, timestep_boundary)
+    return denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cfg_scale=cfg_scale,
+                        return_prediction=return_prediction, topo=topo)
