@@ -17,7 +17,6 @@ self-attention launch, 41% of the forward's FLOPs) and, at N = 1, `cpu_baseline`
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

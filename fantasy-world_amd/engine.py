@@ -15,8 +15,7 @@ Numerics: residual streams (DiT x, VGGT tokens) are kept in fp32 (the reference 
 the VGGT stream in fp32 after the first modulated block); matmul inputs are bf16, accumulation fp32; all
 normalisation statistics, softmax and rotary math are fp32 (tables from fp64).
 """
-import math
-from typing import Callable, Dict, Optional
+from typing import Callable
 
 import torch
 

@@ -14,8 +14,6 @@ its own input sequence (zeros before the start), and the up-sampler passes frame
 history -- so whole-sequence causal convolutions give the same numbers (oracle/fw_heads_oracle.py pins that against the
 chunked reference).  Frames are chunked here only to bound the size of the gathered matrices.
 """
-import math
-
 import torch
 
 from .config import HeadsConfig

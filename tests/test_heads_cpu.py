@@ -1,7 +1,6 @@
 """Host logic of the geometry heads (fantasy_world_amd.heads) on the torch reference op set: weight packing
 (tap-major, channel padding), the whole-sequence form of the cached temporal decode, the ReLU placement of the
 ResidualConvUnits, frame chunking -- against the oracle and the reference's golden prediction dict."""
-import pytest
 import torch
 
 from conftest import PRED_KEYS, rel_l2
