@@ -933,7 +933,9 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     // tile choice: the 256x256 staggered kernel for the big token-major GEMMs, 128x128 otherwise.
     // FW_GEMM_TILE=128|256 forces one (A/B measurements).
     const int forced = fw_get_option(FW_OPT_GEMM_TILE);
-    bool big = (M >= 2048 && N >= 1024);
+    // (narrow outputs qualify once there are two full rounds of 256x256 tiles anyway: the geometry heads' convolutions are
+    // GEMMs with N = 256..512 over hundreds of thousands of pixel rows)
+    bool big = M >= 2048 && (N >= 1024 || (N >= 256 && (int64_t)(M / TM) * ((N + TN - 1) / TN) >= 512));
     if (forced == 128) big = false;
     if (forced == 256) big = true;
     // the 256 kernel's epilogue moves 4 columns per lane: needs N, ldc, ldr % 4 == 0 and 16-B (fp32) / 8-B (bf16) bases

@@ -2,12 +2,13 @@
 (dim 2048, features 256, channels 256/512/1024/1024) -> pose_enc [1,81,9], depth / world_points [1,81,480,832,*].
 Prints wall time per stage, peak memory, and the sanity properties (finite, confidences > 1, depth > 0)."""
 import argparse
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fantasy_world_amd import config as fwc, synth                 # noqa: E402
 from fantasy_world_amd.heads import GeometryHeads                  # noqa: E402
 from fantasy_world_amd.hip_ops import HipOps                       # noqa: E402
