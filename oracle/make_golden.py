@@ -32,6 +32,9 @@ CASES = {
 HEAD_CASES = {
     "heads_small_s3_4x6": (3, 4, 6),
     "heads_small_s2_5x3": (2, 5, 3),
+    # the reference's real widths (dim 2048, 16-head trunk of depth 4, DPT 256 / 512 / 1024 / 1024, layers 23/17/11/7, patch 16)
+    # on a synthetic 24-entry output_list: 623 M parameters, tiny grid
+    "heads_full_s2_2x3": (2, 2, 3),
 }
 
 
@@ -146,7 +149,7 @@ def main_heads(only):
     for name, (S, ph, pw) in HEAD_CASES.items():
         if only and name not in only:
             continue
-        hc = fwc.HeadsConfig.small()
+        hc = fwc.HeadsConfig() if "_full_" in name else fwc.HeadsConfig.small()
         W = synth.make_heads_weights(hc)
         ol = synth.make_output_list(hc, S, ph, pw)
         vggt = ref_harness.build_reference_heads(hc, W)
@@ -157,7 +160,8 @@ def main_heads(only):
         for k in ref:
             print(f"   oracle vs reference  {k:18s} rel-L2 = {rel(orc[k], ref[k]):.3e}   shape {tuple(ref[k].shape)}")
         golden = {k: v.to(torch.float32).contiguous() for k, v in ref.items()}
-        golden["meta"] = dict(grid=(S, ph, pw), seed_weights=0, seed_tokens=3, torch=torch.__version__, heads="small")
+        golden["meta"] = dict(grid=(S, ph, pw), seed_weights=0, seed_tokens=3, torch=torch.__version__,
+                              heads="full" if "_full_" in name else "small")
         path = os.path.join(ROOT, "tests", "golden", name + ".pt")
         torch.save(golden, path)
         print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")

@@ -77,7 +77,7 @@ class HeadsCase:
         self.name = name
         self.golden = load_golden(name)
         meta = self.golden["meta"]
-        self.hc = fwc.HeadsConfig.small()
+        self.hc = fwc.HeadsConfig() if meta.get("heads") == "full" else fwc.HeadsConfig.small()
         self.S, self.ph, self.pw = meta["grid"]
         self.weights = synth.make_heads_weights(self.hc, seed=meta["seed_weights"])
         self.output_list = synth.make_output_list(self.hc, self.S, self.ph, self.pw, seed=meta["seed_tokens"])
@@ -86,6 +86,12 @@ class HeadsCase:
 @pytest.fixture(scope="session", params=["heads_small_s3_4x6", "heads_small_s2_5x3"])
 def heads_case(request):
     return HeadsCase(request.param)
+
+
+@pytest.fixture(scope="session")
+def heads_case_full():
+    """The reference's real head widths (623 M parameters) on a 2x3 token grid."""
+    return HeadsCase("heads_full_s2_2x3")
 
 
 PRED_KEYS = ("pose_enc", "depth", "depth_conf", "world_points", "world_points_conf")

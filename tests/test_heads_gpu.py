@@ -167,3 +167,14 @@ def test_heads_temporal_decode_is_causal(ops):
         assert a[k].shape[1] == T
         assert torch.equal(a[k][:, :first_touched], b[k][:, :first_touched]), k
         assert not torch.equal(a[k][:, first_touched:], b[k][:, first_touched:]), k
+
+
+def test_heads_full_width_matches_reference_golden(heads_case_full, ops):
+    """Real widths through the kernels (K up to 27 648 in the 3x3x3 convolutions at 1024 channels, 16-head hd-128 camera
+    trunk, 4x4 / 2x2 transposed convolutions): the reference's own prediction on a 2x3 token grid."""
+    pred = _predict(heads_case_full, ops)
+    errs = {k: rel_l2(pred[k], heads_case_full.golden[k]) for k in PRED_KEYS}
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    for k in PRED_KEYS:
+        assert pred[k].shape == heads_case_full.golden[k].shape and torch.isfinite(pred[k]).all(), k
+        assert errs[k] < HEADS_TOL, (k, errs[k])

@@ -69,3 +69,18 @@ def test_oracle_chain_matches_reference_prediction_golden(case_pred):
     pred = fw_heads_oracle.head_prediction(c.weights, col["output_list"], c.hc, f, h2 // 2, w2 // 2)
     for k in PRED_KEYS:
         assert rel_l2(pred[k], c.golden[k]) < 1e-5, k
+
+
+def test_heads_oracle_full_width_golden(heads_case_full):
+    """The reference's real head widths (dim 2048, layers 23/17/11/7, DPT 256/512/1024/1024) on a synthetic 24-entry
+    output_list: oracle and host logic (torch ops) against the reference's prediction."""
+    from conftest import PRED_KEYS
+    from fantasy_world_amd import heads as fw_heads
+    from oracle import fw_heads_oracle, ref_ops
+    c = heads_case_full
+    pred = fw_heads_oracle.head_prediction(c.weights, c.output_list, c.hc, c.S, c.ph, c.pw)
+    got = fw_heads.GeometryHeads(c.hc, c.weights.__getitem__, ref_ops.TorchRefOps()).predict(
+        {k: v[None] for k, v in c.output_list.items()}, c.S, c.ph, c.pw)
+    for k in PRED_KEYS:
+        assert rel_l2(pred[k], c.golden[k]) < 5e-6, k
+        assert rel_l2(got[k], c.golden[k]) < 2e-5, k
