@@ -68,6 +68,7 @@ class FusionEngine:
         self.heads_cfg = heads_cfg
         self._heads = None
         self._get = get
+        self.exchange_groups = 2       # head groups per DiT self-attention exchange under a sequence shard (1 = one exchange)
         self._tables = {}
         self._plucker_zero_cache = None
         ops_ = ops
@@ -225,8 +226,9 @@ class FusionEngine:
         ops.qk_prep(k, H, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab)
         st.qkv = qkv
         st.exchange = sh is not None and sh.heads_divisible(H)
-        if st.exchange:      # head exchange: my rows / all heads -> all rows / my heads
-            st.pend = sh.rows_to_heads_async(qkv, 3, sh.dit_counts)
+        if st.exchange:      # head exchange: my rows / all heads -> all rows / my heads, in groups of local heads
+            st.groups = self._head_groups(H // sh.world)
+            st.pend = [sh.rows_to_heads_async(qkv, 3, sh.dit_counts, (a * hd, b * hd)) for a, b in st.groups]
         elif sh is not None:
             st.pend = sh.all_gather_rows_async(qkv[:, D:], sh.dit_counts)      # [L, 2D] (k | v) of every rank
         else:
@@ -237,11 +239,17 @@ class FusionEngine:
         """Attention over the full key sequence; starts the inverse exchange of the output."""
         cfg, ops, sh = self.cfg, self.ops, self.shard
         D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
-        got = st.pend.wait()
         if st.exchange:
-            o = ops.attention(got[:, 0], got[:, 1], got[:, 2], H // sh.world, hd, q_prescaled=True)
-            st.pend = sh.heads_to_rows_async(o, sh.dit_counts)                 # [L/n, D]
+            # group g+1 is still travelling while group g is being attended to, and the output of group g travels back behind
+            # the attention of group g+1: only the first q|k|v group and the last output group are exposed
+            back = []
+            for (a, b), pend in zip(st.groups, st.pend):
+                got = pend.wait()
+                o = ops.attention(got[:, 0], got[:, 1], got[:, 2], b - a, hd, q_prescaled=True)
+                back.append(sh.heads_to_rows_async(o, sh.dit_counts))          # [L/n, world * (b-a) * hd]
+            st.pend = back
         else:
+            got = st.pend.wait()
             k, v = (st.qkv[:, D:2 * D], st.qkv[:, 2 * D:]) if got is None else (got[:, :D], got[:, D:])
             st.pend = Ready(ops.attention(st.qkv[:, :D], k, v, H, hd, q_prescaled=True))
         st.qkv = None
@@ -252,7 +260,17 @@ class FusionEngine:
         cfg, ops = self.cfg, self.ops
         D, H, hd = cfg.dim, cfg.num_heads, cfg.head_dim
         blk, x, mod = st.blk, st.x, st.mod
-        o = st.pend.wait()
+        if st.exchange:
+            if len(st.groups) == 1:
+                o = st.pend[0].wait()
+            else:                                   # columns back into head order: (rank, local head) = global head
+                sh = self.shard
+                o = ops.empty(x.shape[0], D)
+                ov = o.view(x.shape[0], sh.world, D // sh.world)
+                for (a, b), pend in zip(st.groups, st.pend):
+                    ov[:, :, a * hd:b * hd] = pend.wait().view(x.shape[0], sh.world, (b - a) * hd)
+        else:
+            o = st.pend.wait()
         ops.linear(o, blk.o, g1=mod[2], res=x, out_f32=True, out=x)
         # cross-attention: text + image keys share q; outputs are summed (wan_video_dit.py:185-201)
         xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
@@ -274,6 +292,21 @@ class FusionEngine:
             ops.linear(t2, blk.a_v2, res=oc, out=oc)
         ops.linear(oc, blk.co, res=x, out_f32=True, out=x)
         return mod
+
+    def _head_groups(self, local_heads):
+        """Split a rank's heads of the DiT self-attention into groups whose exchanges overlap each other's attention.  Groups
+        hold an even number of heads (2 heads x 128 query blocks = one full round of the 256 CUs at 480p), so a launch on
+        a group wastes no partial round: 10 -> (4, 6), 20 -> (10, 10); odd or small counts stay whole."""
+        n = self.exchange_groups
+        if n <= 1 or local_heads < 4 or local_heads % 2:
+            return [(0, local_heads)]
+        cuts = [0]
+        for g in range(1, n):
+            c = (local_heads * g // n) // 2 * 2
+            if c > cuts[-1]:
+                cuts.append(c)
+        cuts.append(local_heads)
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
 
     def _dit_attn(self, blk, x, ctx_txt, ctx_img, t_mod, tabs, plucker):
         """Self-attention + cross-attention (+ camera adapter), nothing interleaved (the PCB blocks)."""

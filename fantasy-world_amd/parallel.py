@@ -120,14 +120,20 @@ class SequenceShard:
     def heads_divisible(self, heads):
         return heads % self.world == 0
 
-    def rows_to_heads_async(self, t, parts, counts) -> Pending:
+    def rows_to_heads_async(self, t, parts, counts, cols=None) -> Pending:
         """Head exchange, forward direction.  t: this rank's rows [counts[rank], parts*H*hd] laid out as `parts` blocks of
         H*hd columns (q|k|v).  Pending of [sum(counts), parts, (H/world)*hd]: every rank's rows (rank order = token order)
-        for this rank's H/world heads.  One all_to_all_single with uneven row splits."""
+        for this rank's H/world heads.  One all_to_all_single with uneven row splits.
+        cols = (a, b): only columns [a, b) of every rank's (H/world)*hd block -- a group of local heads -- so that the
+        exchange of the next group can run behind the attention of this one."""
         rows, width = t.shape
         assert rows == counts[self.rank] and width % (parts * self.world) == 0, (t.shape, parts, counts)
         c = width // (parts * self.world)                       # (H/world)*hd
-        send = t.reshape(rows, parts, self.world, c).permute(2, 0, 1, 3).contiguous()       # [world, rows, parts, c]
+        src = t.reshape(rows, parts, self.world, c)
+        if cols is not None:
+            src = src[:, :, :, cols[0]:cols[1]]
+            c = cols[1] - cols[0]
+        send = src.permute(2, 0, 1, 3).contiguous()                                         # [world, rows, parts, c]
         out = torch.empty(sum(counts), parts, c, dtype=t.dtype, device=t.device)
         work = dist.all_to_all_single(out.view(sum(counts), parts * c), send.view(self.world * rows, parts * c),
                                       output_split_sizes=list(counts), input_split_sizes=[rows] * self.world,

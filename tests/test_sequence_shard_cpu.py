@@ -172,3 +172,26 @@ def test_head_exchange_roundtrip_layout():
         send = [rows[s].reshape(counts[s], parts, world, c).permute(2, 0, 1, 3)[r] for s in range(world)]
         got = torch.cat(send, dim=0)
         assert torch.equal(got, want)
+
+
+def test_head_groups_and_column_window():
+    """Grouped head exchange: the group boundaries keep whole rounds of the grid, and the column window of
+    rows_to_heads_async selects the same local heads on every rank."""
+    from fantasy_world_amd.engine import FusionEngine
+    eng = FusionEngine.__new__(FusionEngine)
+    eng.exchange_groups = 2
+    assert eng._head_groups(10) == [(0, 4), (4, 10)]          # 8 GPUs: 2 CFG groups x 4 ranks, 40 heads
+    assert eng._head_groups(20) == [(0, 10), (10, 20)]        # 4 GPUs
+    assert eng._head_groups(5) == [(0, 5)] and eng._head_groups(2) == [(0, 2)]
+    eng.exchange_groups = 1
+    assert eng._head_groups(20) == [(0, 20)]
+    # layout of a windowed exchange, by hand for 2 ranks
+    counts, parts, H, hd, world = [3, 2], 3, 8, 2, 2
+    full = torch.arange(sum(counts) * parts * H * hd, dtype=torch.float32).view(sum(counts), parts * H * hd)
+    c = (H // world) * hd
+    a, b = 2 * hd, 4 * hd                                      # local heads 2..3 of every rank
+    for r in range(world):
+        want = full.view(-1, parts, world, c)[:, :, r, a:b]
+        send = [full[(0 if s == 0 else counts[0]):(counts[0] if s == 0 else None)].reshape(counts[s], parts, world, c)[:, :, :, a:b]
+                .permute(2, 0, 1, 3)[r] for s in range(world)]
+        assert torch.equal(torch.cat(send, dim=0), want)
