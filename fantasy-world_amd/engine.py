@@ -53,15 +53,49 @@ class _Stage:
     pass
 
 
+class _InvariantCache:
+    """Step-invariant intermediates: values that depend only on tensors the caller passes unchanged
+    through all 50 x 2 forwards of a generation -- the context embeddings (A2), every block's cross-attention K/V (A8), the
+    camera adapter's Pluecker term (A9).  Keyed on the identity of the source tensors (address, shape, dtype, in-place version
+    counter); the entry keeps the sources alive, so their storage cannot be recycled under the same address.  A few entries
+    per tag (positive / negative prompt).  Disabled = every call recomputes, exactly like the reference."""
+
+    def __init__(self, enabled, per_tag=4):
+        self.enabled, self.per_tag, self.entries = enabled, per_tag, {}
+
+    @staticmethod
+    def _ident(t):
+        return (t.data_ptr(), tuple(t.shape), str(t.dtype), t._version, str(t.device))
+
+    def get(self, tag, sources, fn):
+        if not self.enabled:
+            return fn()
+        key = tuple(self._ident(t) for t in sources)
+        slot = self.entries.setdefault(tag, [])
+        for i, (k, val, _) in enumerate(slot):
+            if k == key:
+                slot.append(slot.pop(i))                    # most recently used last
+                return val
+        val = fn()
+        slot.append((key, val, tuple(sources)))
+        del slot[:-self.per_tag]
+        return val
+
+    def clear(self):
+        self.entries.clear()
+
+
 class FusionEngine:
     """Holds the pre-packed weights of one fusion model on one device and runs joint_forward on it."""
 
-    def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None, heads_cfg=None):
+    def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None, heads_cfg=None,
+                 cache_step_invariants=False):
         """`get(name)` returns the reference parameter `name` (any dtype/device); tensors are packed block by block
         so a 14B model never needs a second full-precision copy.  `shard` is an optional
         fantasy_world_amd.parallel.SequenceShard (one process per GPU, RCCL).  `heads_cfg` (config.HeadsConfig) enables the
         geometry heads: joint_forward(return_prediction=True) then returns the reference's prediction dict
-        (vggt.py:134-154); their weights are packed on first use."""
+        (vggt.py:134-154); their weights are packed on first use.  `cache_step_invariants` keeps the intermediates that
+        only depend on the prompt / camera inputs across calls (same results, bit for bit; see _InvariantCache)."""
         self.cfg = cfg
         self.ops = ops
         self.shard = shard
@@ -69,6 +103,8 @@ class FusionEngine:
         self._heads = None
         self._get = get
         self.exchange_groups = 2       # head groups per DiT self-attention exchange under a sequence shard (1 = one exchange)
+        # Off by default: bench.py measures the reference's per-step work.  install() turns it on for real generations.
+        self.invariants = _InvariantCache(cache_step_invariants)
         self._tables = {}
         self._plucker_zero_cache = None
         ops_ = ops
@@ -276,17 +312,27 @@ class FusionEngine:
         xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
         qc = ops.linear(xn3, blk.cq)
         ops.qk_prep(qc, H, hd, norm="rms_full", norm_w=blk.cnorm_q, eps=cfg.eps, out_scale=ops.q_scale(hd))
-        kv = ops.linear(ctx_txt, blk.ckv)
-        ops.qk_prep(kv[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k, eps=cfg.eps)
-        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd, q_prescaled=True)
-        if ctx_img is not None:
+        def text_kv():
+            kv = ops.linear(ctx_txt, blk.ckv)
+            ops.qk_prep(kv[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k, eps=cfg.eps)
+            return kv
+
+        def image_kv():
             kvi = ops.linear(ctx_img, blk.ckv_img)
             ops.qk_prep(kvi[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k_img, eps=cfg.eps)
+            return kvi
+
+        kv = self.invariants.get(("ckv", id(blk)), (ctx_txt,), text_kv)
+        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd, q_prescaled=True)
+        if ctx_img is not None:
+            kvi = self.invariants.get(("ckv_img", id(blk)), (ctx_img,), image_kv)
             ops.attention(qc, kvi[:, :D], kvi[:, D:], H, hd, out=oc, accumulate=True, q_prescaled=True)
         if blk.adapter and plucker is not None:
             # camera_control.py:109-127 ('adaln'): scale == 0 identically, so x <- x + shift
             t1 = ops.linear(oc, blk.a_g20, act="relu")
-            pterm = ops.linear(plucker, blk.a_g1)
+            pterm = self.invariants.get(("pterm", id(blk)), (plucker,), lambda: ops.linear(plucker, blk.a_g1))
+            if self.invariants.enabled:
+                pterm = pterm.clone()                       # the next GEMM accumulates into its residual operand
             comb = ops.linear(t1, blk.a_g22, res=pterm, out=pterm)
             t2 = ops.linear(comb, blk.a_v0, act="relu")
             ops.linear(t2, blk.a_v2, res=oc, out=oc)
@@ -461,12 +507,15 @@ class FusionEngine:
         e0 = ops.linear_f32(ev, self.vtimep, silu_in=True).view(6, cfg.vggt_dim)
 
         # ---- A2: context embeddings (wan_video_dit.py:388-392, 324-341) ----------------------------------------
-        ctx_txt = ops.linear(ops.linear(ops.to_act(context[0]), self.text0, act="gelu_tanh"), self.text2)
+        ctx_txt = self.invariants.get("ctx_txt", (context,), lambda: ops.linear(
+            ops.linear(ops.to_act(context[0]), self.text0, act="gelu_tanh"), self.text2))
         ctx_img = None
         if cfg.has_image_input:
-            ci = ops.layernorm(ops.to_act(clip_feature[0]), w=self.img_ln0[0], b=self.img_ln0[1], eps=1e-5)
-            ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
-            ctx_img = ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
+            def image_ctx():
+                ci = ops.layernorm(ops.to_act(clip_feature[0]), w=self.img_ln0[0], b=self.img_ln0[1], eps=1e-5)
+                ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
+                return ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
+            ctx_img = self.invariants.get("ctx_img", (clip_feature,), image_ctx)
 
         # ---- A3: patchify (Conv3d k=s=(1,2,2) as GEMM) ---------------------------------------------------------
         # Wan2.1 concatenates y when the DiT has image input (model_wan21.py:125-126), Wan2.2 whenever y is given (model_wan22.py:252-253)
@@ -478,10 +527,10 @@ class FusionEngine:
         plucker = None
         if plucker_fea is not None and cfg.camera_adapter:
             if not self._plucker_all_zero(plucker_fea):                                        # camera_control.py:111
-                plucker = ops.to_act(plucker_fea[0])
+                plucker = self.invariants.get("plucker_rows", (plucker_fea,), lambda: (
+                    ops.to_act(plucker_fea[0]) if sh is None else sh.take_dit_rows(ops.to_act(plucker_fea[0]))))
         if sh is not None:
             patches = sh.take_dit_rows(patches)
-            plucker = None if plucker is None else sh.take_dit_rows(plucker)
             ycam = None if ycam is None else sh.take_dit_rows(ycam)
         xs = ops.linear(patches, self.patch, res=ycam, out_f32=True)                          # fp32 residual stream
 

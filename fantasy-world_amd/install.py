@@ -58,15 +58,18 @@ def heads_config_from_model(vggt):
         point_out=pts.scratch.output_conv2[2].out_channels)
 
 
-def install(model, ops=None, device=None):
+def install(model, ops=None, device=None, cache_step_invariants=True):
     """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
-    tests may inject another op set to exercise this boundary on CPU."""
+    tests may inject another op set to exercise this boundary on CPU.  `cache_step_invariants`: keep the context embeddings,
+    the per-block cross-attention K/V and the camera adapter's Pluecker term across the calls of a generation (the caller
+    passes the same tensors 100 times; results are bit-identical)."""
     if ops is None:
         from .hip_ops import HipOps
         ops = HipOps(device or "cuda")
     cfg = config_from_model(model)
     params = dict(model.named_parameters())
-    engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt))
+    engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
+                          cache_step_invariants=cache_step_invariants)
 
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
                       camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,

@@ -84,3 +84,52 @@ def test_engine_return_prediction_matches_reference_golden(case_pred):
     eng2 = FusionEngine(c.cfg, c.weights.__getitem__, TorchRefOps())
     _, outputs = eng2.joint_forward(ins["x"], ins["timestep"], ins["context"], return_prediction=True, **forward_kwargs(c))
     assert all(v.shape[-1] == 2 * c.cfg.vggt_dim for v in outputs.values()) and (c.cfg.n_irg - 1) in outputs
+
+
+def test_step_invariant_cache_is_exact_and_skips_work(case_l2):
+    """with cache_step_invariants the second and later calls reuse the context embeddings, every
+    block's cross-attention K/V and the adapter's Pluecker term -- bit-identical outputs, fewer GEMMs; a new or modified
+    context tensor is recomputed."""
+    from conftest import forward_kwargs
+    c, ins = case_l2, case_l2.inputs
+    kw = forward_kwargs(c)
+
+    class CountingOps(TorchRefOps):
+        def __init__(self):
+            super().__init__()
+            self.n_linear = 0
+
+        def linear(self, *a, **k):
+            self.n_linear += 1
+            return super().linear(*a, **k)
+
+    plain_ops, cached_ops = CountingOps(), CountingOps()
+    plain = FusionEngine(c.cfg, c.weights.__getitem__, plain_ops)
+    cached = FusionEngine(c.cfg, c.weights.__getitem__, cached_ops, cache_step_invariants=True)
+    t2 = ins["timestep"] * 0.5
+    want1, _ = plain.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+    n_plain = plain_ops.n_linear
+    want2, _ = plain.joint_forward(ins["x"], t2, ins["context"], **kw)
+    got1, _ = cached.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+    n_first = cached_ops.n_linear
+    got2, _ = cached.joint_forward(ins["x"], t2, ins["context"], **kw)
+    n_second = cached_ops.n_linear - n_first
+    assert torch.equal(got1, want1) and torch.equal(got2, want2)
+    assert n_first == n_plain
+    # per DiT block: text K/V, image K/V and the adapter's Pluecker GEMM drop out; plus 2 text-embedding and 2 image-embedding GEMMs
+    assert n_second == n_plain - (3 * c.cfg.num_layers + 4), (n_plain, n_second)
+    # a different context tensor (the negative prompt) gets its own entries, and coming back to the first one hits
+    neg = ins["context_neg"]
+    want3, _ = plain.joint_forward(ins["x"], t2, neg, **kw)
+    got3, _ = cached.joint_forward(ins["x"], t2, neg, **kw)
+    assert torch.equal(got3, want3)
+    before = cached_ops.n_linear
+    got4, _ = cached.joint_forward(ins["x"], t2, ins["context"], **kw)
+    assert torch.equal(got4, want2) and cached_ops.n_linear - before == n_second
+    # an in-place edit of the context bumps its version counter: recomputed, not served stale
+    ctx = ins["context"].clone()
+    a, _ = cached.joint_forward(ins["x"], t2, ctx, **kw)
+    ctx.mul_(0.5)
+    b, _ = cached.joint_forward(ins["x"], t2, ctx, **kw)
+    ref_b, _ = plain.joint_forward(ins["x"], t2, ctx, **kw)
+    assert torch.equal(a, want2) and torch.equal(b, ref_b) and not torch.equal(a, b)
