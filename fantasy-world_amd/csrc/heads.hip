@@ -36,7 +36,7 @@ __device__ __forceinline__ u32x4_t relu8(u32x4_t v) {
 // zero outside the volume: causal in time, 'same' in space.  One work-item per (output row, tap, 8 channels).
 __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
                                                      int64_t ldo, int C8, int T, int H, int W, int Ho, int Wo, int kt, int kh,
-                                                     int kw, int sh, int sw, int t0, int64_t total, int relu_in) {
+                                                     int kw, int sh, int sw, int ph, int pw, int t0, int64_t total, int relu_in) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int c8 = (int)(gid % C8);
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict_
     const int tt = (int)(r / ((int64_t)Wo * Ho));
     const int dx = tap % kw, dy = (tap / kw) % kh, dt = tap / (kw * kh);
     const int ti = t0 + tt + dt - (kt - 1);
-    const int yi = yo * sh + dy - kh / 2;
-    const int xi = xo * sw + dx - kw / 2;
+    const int yi = yo * sh + dy - ph;
+    const int xi = xo * sw + dx - pw;
     u32x4_t v = {0u, 0u, 0u, 0u};
     if (ti >= 0 && ti < T && yi >= 0 && yi < H && xi >= 0 && xi < W) {
         v = *(const u32x4_t*)(x + (((int64_t)ti * H + yi) * W + xi) * ldx + c8 * 8);
@@ -228,23 +228,130 @@ __global__ __launch_bounds__(256) void head_activation_kernel(const float* __res
     conf[r] = 1.f + expf(src[n - 1]);
 }
 
+// nn.PixelUnshuffle(r) on a channels-last image stack (pose_adaptor_ac3d.py:26,91): in [F][H][W][C] (f32 or bf16) ->
+// out [(f, y, x)][c*r*r + dy*r + dx] = in[f][y*r + dy][x*r + dx][c], bf16.  One work-item per output element pair.
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_unshuffle_kernel(const T* __restrict__ in, uint16_t* __restrict__ out, int64_t ldo,
+                                                              int H, int W, int C, int r, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int K = C * r * r;
+    const int col = (int)(gid % (K / 2)) * 2;
+    const int64_t row = gid / (K / 2);
+    const int w = W / r, h = H / r;
+    const int x = (int)(row % w), y = (int)((row / w) % h);
+    const int64_t f = row / ((int64_t)w * h);
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cc = col + j;
+        const int c = cc / (r * r), dy = (cc / r) % r, dx = cc % r;
+        const T e = in[((f * H + (y * r + dy)) * W + (x * r + dx)) * C + c];
+        if constexpr (sizeof(T) == 2) v[j] = bf16_bits_to_f32(e); else v[j] = e;
+    }
+    *(uint32_t*)(out + row * ldo + col) = pack_bf16x2(v[0], v[1]);
+}
+
+// nn.GroupNorm(G, C) on channels-last rows [frames*hw][C] (pose_adaptor_ac3d.py:30-40): statistics per (frame, group) over
+// hw x C/G values, biased variance, then y = (x - mean) * rstd * w[c] + b[c] (+ ReLU).  One work-group per (frame, group):
+// the slab (a few MB at most) is read twice, fp32 accumulation.
+__global__ __launch_bounds__(1024) void group_norm_rows_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                               int64_t ldo, int hw, int C, int G, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float eps, int relu) {
+    __shared__ float red[2][16];
+    const int f = blockIdx.x / G, g = blockIdx.x % G;
+    const int cg = C / G, c8n = cg / 8;
+    const uint16_t* src = x + (int64_t)f * hw * ldx + g * cg;
+    const int64_t n8 = (int64_t)hw * c8n;
+    float s = 0.f, ss = 0.f;
+    for (int64_t i = threadIdx.x; i < n8; i += 1024) {
+        const int64_t p = i / c8n;
+        const int c8 = (int)(i % c8n);
+        float v[8];
+        unpack8(*(const u32x4_t*)(src + p * ldx + c8 * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += v[j]; ss += v[j] * v[j]; }
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    s = 0.f; ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s += red[0][j]; ss += red[1][j]; }
+    const float cnt = (float)hw * (float)cg;
+    const float mean = s / cnt;
+    const float rstd = rsqrtf(fmaxf(ss / cnt - mean * mean, 0.f) + eps);
+    uint16_t* dst = out + (int64_t)f * hw * ldo + g * cg;
+    for (int64_t i = threadIdx.x; i < n8; i += 1024) {
+        const int64_t p = i / c8n;
+        const int c8 = (int)(i % c8n);
+        float v[8];
+        unpack8(*(const u32x4_t*)(src + p * ldx + c8 * 8), v);
+        const float* wp = w + g * cg + c8 * 8;
+        const float* bp = b + g * cg + c8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (v[j] - mean) * rstd * wp[j] + bp[j];
+            if (relu) v[j] = fmaxf(v[j], 0.f);
+        }
+        *(u32x4_t*)(dst + p * ldo + c8 * 8) = pack8(v);
+    }
+}
+
+// CameraPoseEncoder.compress_time (pose_adaptor_ac3d.py:61-76) on rows [frames*hw][C]: odd frame count keeps frame 0 and
+// averages frames (2i+1, 2i+2); even averages (2i, 2i+1).  One work-item per 8 channels of an output row.
+__global__ __launch_bounds__(256) void time_avg_pool_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
+                                                            int64_t ldo, int C8, int hw, int odd, int64_t total) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c8 = (int)(gid % C8);
+    const int64_t r = gid / C8;
+    const int64_t p = r % hw, fo = r / hw;
+    u32x4_t res;
+    if (odd && fo == 0) {
+        res = *(const u32x4_t*)(x + p * ldx + c8 * 8);
+    } else {
+        const int64_t fa = odd ? 2 * fo - 1 : 2 * fo;
+        float a[8], b[8];
+        unpack8(*(const u32x4_t*)(x + (fa * hw + p) * ldx + c8 * 8), a);
+        unpack8(*(const u32x4_t*)(x + ((fa + 1) * hw + p) * ldx + c8 * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (a[j] + b[j]) * 0.5f;
+        res = pack8(a);
+    }
+    *(u32x4_t*)(out + r * ldo + c8 * 8) = res;
+}
+
+// out = act(x) on a contiguous bf16 tensor (the GELU between LayerNorm and Linear in CameraPoseEncoder.fc, pose_adaptor_ac3d.py:43-48)
+__global__ __launch_bounds__(256) void activation_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, int64_t n8, int act) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n8) return;
+    float v[8];
+    unpack8(*(const u32x4_t*)(x + gid * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fw_apply_act(v[j], act);
+    *(u32x4_t*)(out + gid * 8) = pack8(v);
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
 extern "C" int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh,
-                         int kw, int sh, int sw, int t0, int nt, int relu_in, void* stream) {
+                         int kw, int sh, int sw, int ph, int pw, int t0, int nt, int relu_in, void* stream) {
     if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out)) {
         fw_set_error("fw_im2col: C, ldx, ldo must be multiples of 8 and the bases 16-byte aligned"); return FW_E_BADARG; }
-    if (kt < 1 || kh < 1 || kw < 1 || !(kh & 1) || !(kw & 1) || sh < 1 || sw < 1 || t0 < 0 || nt < 0 || t0 + nt > T) {
-        fw_set_error("fw_im2col: bad kernel / stride / frame window"); return FW_E_BADARG; }
-    const int Ho = (H + 2 * (kh / 2) - kh) / sh + 1, Wo = (W + 2 * (kw / 2) - kw) / sw + 1;
+    if (kt < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || t0 < 0 || nt < 0 || t0 + nt > T ||
+        H + 2 * ph < kh || W + 2 * pw < kw) {
+        fw_set_error("fw_im2col: bad kernel / stride / padding / frame window"); return FW_E_BADARG; }
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
     const int64_t total = (int64_t)nt * Ho * Wo * kt * kh * kw * (C / 8);
     if (total <= 0) return 0;
     if ((total + 255) / 256 > 0x7fffffffLL) { fw_set_error("fw_im2col: grid too large, chunk the frames"); return FW_E_BADARG; }
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, C / 8, T, H, W,
-                       Ho, Wo, kt, kh, kw, sh, sw, t0, total, relu_in);
+                       Ho, Wo, kt, kh, kw, sh, sw, ph, pw, t0, total, relu_in);
     return (int)hipGetLastError();
 }
 
@@ -319,5 +426,48 @@ extern "C" int fw_head_activation(const float* y, int64_t rows, int n, int mode,
     if (!y || !pts || n < 2 || mode < 0 || mode > 2 || (mode != 2 && !conf)) { fw_set_error("fw_head_activation: bad arguments"); return FW_E_BADARG; }
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(head_activation_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, y, rows, n, mode, pts, conf);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_pixel_unshuffle(const void* in, int dtype, uint16_t* out, int64_t ldo, int F, int H, int W, int C, int r, void* stream) {
+    if (!in || !out || r < 1 || (H % r) || (W % r) || ((C * r * r) % 2) || (ldo % 2) || (((uintptr_t)out) & 3) ||
+        (dtype != FW_DT_BF16 && dtype != FW_DT_F32)) {
+        fw_set_error("fw_pixel_unshuffle: H, W must be multiples of r, C*r*r and ldo even, dtype bf16 or f32"); return FW_E_BADARG; }
+    const int64_t total = (int64_t)F * (H / r) * (W / r) * (C * r * r / 2);
+    if (total <= 0) return 0;
+    if (dtype == FW_DT_F32)
+        hipLaunchKernelGGL(pixel_unshuffle_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)in, out,
+                           ldo, H, W, C, r, total);
+    else
+        hipLaunchKernelGGL(pixel_unshuffle_kernel<uint16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t*)in, out, ldo, H, W, C, r, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_group_norm_rows(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int frames, int hw, int C, int groups,
+                                  const float* w, const float* b, float eps, int relu, void* stream) {
+    if (!w || !b || groups < 1 || C <= 0 || (C % groups) || ((C / groups) % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out)) {
+        fw_set_error("fw_group_norm_rows: C/groups must be a multiple of 8, rows 16-byte aligned"); return FW_E_BADARG; }
+    if (frames <= 0 || hw <= 0) return 0;
+    hipLaunchKernelGGL(group_norm_rows_kernel, dim3((unsigned)(frames * groups)), dim3(1024), 0, (hipStream_t)stream, x, ldx, out, ldo,
+                       hw, C, groups, w, b, eps, relu);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_time_avg_pool(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int frames, int hw, int C, void* stream) {
+    if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out) || frames < 1) {
+        fw_set_error("fw_time_avg_pool: bad arguments"); return FW_E_BADARG; }
+    const int odd = frames & 1;
+    const int fout = odd ? 1 + (frames - 1) / 2 : frames / 2;
+    const int64_t total = (int64_t)fout * hw * (C / 8);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(time_avg_pool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, C / 8, hw, odd, total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_activation(const uint16_t* x, uint16_t* out, int64_t n, int act, void* stream) {
+    if ((n % 8) || !aligned16(x) || !aligned16(out)) { fw_set_error("fw_activation: n % 8 == 0 and 16-byte bases required"); return FW_E_BADARG; }
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(activation_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, out, n / 8, act);
     return (int)hipGetLastError();
 }

@@ -25,6 +25,7 @@ SYMBOLS = [
     "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_control_patchify", "fw_im2col3x3",
     "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
+    "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation",
 ]
 
 _lib = None
@@ -62,7 +63,11 @@ def load_library(path: str = LIB_PATH):
         "fw_debug_attention_timestamps": [vp, i32],
         "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
-        "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+        "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+        "fw_pixel_unshuffle": [vp, i32, vp, i64, i32, i32, i32, i32, i32, vp],
+        "fw_group_norm_rows": [vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp],
+        "fw_time_avg_pool": [vp, i64, vp, i64, i32, i32, i32, vp],
+        "fw_activation": [vp, vp, i64, i32, vp],
         "fw_resize_bilinear": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp],
         "fw_chan_rmsnorm_silu": [vp, i64, vp, i64, i64, i32, i32, vp, vp],
         "fw_depth_to_space": [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
@@ -76,7 +81,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    if lib.fw_abi_version() != 3:
+    if lib.fw_abi_version() != 4:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -329,16 +334,51 @@ class HipOps:
     def _bf16_rows(self, x):
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0, (x.dtype, x.shape)
 
-    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False):
+    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False, ph=None, pw=None):
         """Gather of a convolution as GEMM (fw_im2col): [T*H*W, C] -> [nt*Ho*Wo, kt*kh*kw*C], tap-major columns."""
         self._bf16_rows(x)
         assert x.shape[0] == T * H * W
         nt = T - t0 if nt is None else nt
+        ph, pw = kh // 2 if ph is None else ph, kw // 2 if pw is None else pw
         C = x.shape[1]
-        Ho, Wo = (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         out = torch.empty(nt * Ho * Wo, kt * kh * kw * C, dtype=torch.bfloat16, device=self.device)
         _check(self.lib.fw_im2col(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), C, T, H, W, kt, kh, kw, sh, sw,
-                                  t0, nt, int(relu_in), self._stream()), "fw_im2col")
+                                  ph, pw, t0, nt, int(relu_in), self._stream()), "fw_im2col")
+        return out
+
+    # ---- camera pose encoder (SURVEY.md A21) ---------------------------------------------------------------------------
+    def pixel_unshuffle_rows(self, x, r):
+        assert x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32), (x.shape, x.dtype)
+        Fr, H, W, C = x.shape
+        out = torch.empty(Fr * (H // r) * (W // r), C * r * r, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_pixel_unshuffle(x.data_ptr(), _dt(x), out.data_ptr(), out.stride(0), Fr, H, W, C, r, self._stream()),
+               "fw_pixel_unshuffle")
+        return out
+
+    def group_norm_rows(self, x, frames, groups, w, b, eps=1e-5, relu=False):
+        self._bf16_rows(x)
+        rows, C = x.shape
+        assert rows % frames == 0 and w.dtype == torch.float32 and b.dtype == torch.float32 and w.numel() == C
+        out = torch.empty_like(x)
+        _check(self.lib.fw_group_norm_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), frames, rows // frames, C,
+                                           groups, w.data_ptr(), b.data_ptr(), float(eps), int(relu), self._stream()),
+               "fw_group_norm_rows")
+        return out
+
+    def time_avg_pool(self, x, frames, hw):
+        self._bf16_rows(x)
+        assert x.shape[0] == frames * hw
+        fout = 1 + (frames - 1) // 2 if frames % 2 else frames // 2
+        out = torch.empty(fout * hw, x.shape[1], dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_time_avg_pool(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), frames, hw, x.shape[1],
+                                         self._stream()), "fw_time_avg_pool")
+        return out, fout
+
+    def activation(self, x, act):
+        assert x.dtype == torch.bfloat16 and x.is_contiguous()
+        out = torch.empty_like(x)
+        _check(self.lib.fw_activation(x.data_ptr(), out.data_ptr(), x.numel(), ACT[act], self._stream()), "fw_activation")
         return out
 
     def resize_bilinear(self, x, N, h, w, H, W):

@@ -8,6 +8,7 @@
 
 The replacement keeps the reference signature and return convention
 (FantasyWorld/fusion/model_wan21.py:104-116,217-224): (noise_pred[B,16,F,H,W] in x.dtype, prediction dict | None).
+On a Wan2.1 model `camera_condition.get_pose_fea` (the once-per-generation CameraPoseEncoder) is rebound too.
 The once-per-generation geometry heads (vggt._head_predction, vggt/models/vggt.py:134-154) run on the same
 engine (fantasy_world_amd.heads) when the model carries all three of them; a VGGT with a head switched off keeps the
 reference's own head modules on the aggregated tokens the engine returns.
@@ -101,6 +102,23 @@ def install(model, ops=None, device=None, cache_step_invariants=True):
     model._fw_reference_joint_forward = model.joint_forward
     model.joint_forward = types.MethodType(joint_forward22 if cfg.control_adapter else joint_forward, model)
     model._fw_engine = engine
+
+    # Wan2.1: the producer of plucker_fea (CameraConditionModel.get_pose_fea, camera_control.py:233-234; called once per
+    # generation from generate_video, model_wan21.py:271) moves onto the same op set; packed on first use
+    cam = getattr(model, "camera_condition", None)
+    if cam is not None and getattr(cam, "pose_encoder", None) is not None and getattr(cam.pose_encoder, "pose_inject_method", "") == "adaln":
+        state = {}
+
+        def get_pose_fea(self, plucker):
+            if plucker is None:
+                return None
+            if "enc" not in state:
+                from .pose_encoder import PoseEncoder
+                state["enc"] = PoseEncoder(dict(model.named_parameters()).__getitem__, ops)
+            return state["enc"].encode(plucker)
+
+        cam._fw_reference_get_pose_fea = cam.get_pose_fea
+        cam.get_pose_fea = types.MethodType(get_pose_fea, cam)
     return engine
 
 
@@ -109,6 +127,10 @@ def uninstall(model):
         model.joint_forward = model._fw_reference_joint_forward
         del model._fw_reference_joint_forward
         del model._fw_engine
+    cam = getattr(model, "camera_condition", None)
+    if cam is not None and hasattr(cam, "_fw_reference_get_pose_fea"):
+        cam.get_pose_fea = cam._fw_reference_get_pose_fea
+        del cam._fw_reference_get_pose_fea
 
 
 def install_flash_attention(modules, ops=None, device=None, name="flash_attention"):

@@ -285,3 +285,41 @@ def make_output_list(hc: HeadsConfig, S: int, ph: int, pw: int, n_special=5, see
         g = torch.Generator(device="cpu").manual_seed(1000 * seed + layer)
         out[layer] = (torch.randn(S, n_special + ph * pw, hc.dim_in, generator=g) * 2.0).to(device)
     return out
+
+
+def pose_encoder_weight_spec(dim=5120, context_dim=2048, in_channels=6, pre="camera_condition.pose_encoder."):
+    """CameraPoseEncoder parameters (diffsynth_wan21/models/pose_adaptor_ac3d.py:10-48)."""
+    spec = OrderedDict()
+    c0 = in_channels * 64
+    p = pre + "controlnet_encode_first."
+    _conv(spec, p + "0", (c0, c0, 1, 1))
+    _conv(spec, p + "2", (c0, c0, 1, 1))
+    for n, c in (("1", c0), ("3", c0)):
+        spec[p + n + ".weight"] = ((c,), ("ones_normal", 0.1))
+        spec[p + n + ".bias"] = ((c,), ("normal", 0.05))
+    p = pre + "controlnet_encode_second."
+    _conv(spec, p + "0", (2 * c0, c0, 1, 1))
+    spec[p + "1.weight"] = ((2 * c0,), ("ones_normal", 0.1))
+    spec[p + "1.bias"] = ((2 * c0,), ("normal", 0.05))
+    _conv(spec, pre + "patch_embedding", (dim, 2 * c0, 1, 2, 2))
+    p = pre + "fc."
+    _lin(spec, p + "0", dim // 2, dim)
+    _lin(spec, p + "3", context_dim, dim // 2)
+    for n, c in (("1", dim // 2), ("4", context_dim)):
+        spec[p + n + ".weight"] = ((c,), ("ones_normal", 0.1))
+        spec[p + n + ".bias"] = ((c,), ("normal", 0.05))
+    return spec
+
+
+def make_pose_encoder_weights(device="cpu", seed=0, bf16_round=True, **kw):
+    out = OrderedDict()
+    for name, (shape, init) in pose_encoder_weight_spec(**kw).items():
+        t = make_param(name, shape, init, device=device, dtype=torch.float32, seed=seed)
+        out[name] = t.to(torch.bfloat16).to(torch.float32) if bf16_round else t
+    return out
+
+
+def make_plucker(frames, H, W, channels=6, seed=5, device="cpu"):
+    """Synthetic Pluecker embedding [1, frames, H, W, 6] (unit-scale ray moments / directions), bf16-representable."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(1, frames, H, W, channels, generator=g).to(torch.bfloat16).float().to(device)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 3
+#define FW_ABI_VERSION 4
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -215,11 +215,12 @@ int fw_im2col3x3(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int
 /*
  * Gather for nn.Conv2d 3x3 (stride 1 or 2, padding 1: vggt/heads/dpt_head.py:82-87, 352-397, 412-428) and CausalConv3d
  * (wan/modules/vae_modified.py:17-36; kernels (3,1,1) and (3,3,3)).  x [T*H*W][C] -> out rows (t - t0, yo, xo) for output
- * frames t0..t0+nt-1, column ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][yo*sh + dy - kh/2][xo*sw + dx - kw/2][c], zero
- * outside the volume (causal in time, 'same' in space).  relu_in applies ReLU to the gathered values.
+ * frames t0..t0+nt-1, column ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][yo*sh + dy - ph][xo*sw + dx - pw][c], zero
+ * outside the volume (causal in time; ph / pw = k/2 gives 'same', 0 the patch embedding Conv3d(k = s = (1,2,2)) of
+ * CameraPoseEncoder, pose_adaptor_ac3d.py:40-41).  relu_in applies ReLU to the gathered values.
  */
 int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh, int kw,
-              int sh, int sw, int t0, int nt, int relu_in, void* stream);
+              int sh, int sw, int ph, int pw, int t0, int nt, int relu_in, void* stream);
 
 /* F.interpolate(mode="bilinear", align_corners=True) (custom_interpolate, vggt/heads/dpt_head.py:538-566):
  * x [N*h*w][C] -> out [N*H*W][C]. */
@@ -253,6 +254,28 @@ int fw_adaln_rows(const float* x, const float* mod, float* out, int rows, int C,
  * mode 0 "exp": pts[rows][n-1] = exp(.), conf = 1 + exp(y[:, n-1]); mode 1 "inv_log": pts = sign(v) expm1(|v|), same conf;
  * mode 2 "pose": pts[rows][n] = y with ReLU on columns >= 7 (conf unused). */
 int fw_head_activation(const float* y, int64_t rows, int n, int mode, float* pts, float* conf, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * CameraPoseEncoder (FantasyWorld/diffsynth_wan21/models/pose_adaptor_ac3d.py:83-118, called once per
+ * generation through CameraConditionModel.get_pose_fea, camera_control.py:233-234): the pieces around fw_gemm_bf16.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* nn.PixelUnshuffle(r) (pose_adaptor_ac3d.py:26,91): in [F][H][W][C] (bf16 or f32, the Pluecker embedding as the caller
+ * holds it) -> out [(f, y, x)][c*r*r + dy*r + dx] = in[f][y*r + dy][x*r + dx][c], bf16 rows (ldo). */
+int fw_pixel_unshuffle(const void* in, int dtype, uint16_t* out, int64_t ldo, int F, int H, int W, int C, int r, void* stream);
+
+/* nn.GroupNorm(groups, C) (+ ReLU) on channels-last rows [frames*hw][C] (pose_adaptor_ac3d.py:30-40): statistics per
+ * (frame, group) over hw x C/groups values, biased variance, affine w/b per channel. */
+int fw_group_norm_rows(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int frames, int hw, int C, int groups,
+                       const float* w, const float* b, float eps, int relu, void* stream);
+
+/* CameraPoseEncoder.compress_time (pose_adaptor_ac3d.py:61-76): rows [frames*hw][C] -> [frames'*hw][C]; an odd frame count keeps
+ * frame 0 and averages the rest in pairs (frames' = 1 + (frames-1)/2), an even one averages all pairs. */
+int fw_time_avg_pool(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int frames, int hw, int C, void* stream);
+
+/* out = act(x) (FW_ACT_*) on a contiguous bf16 tensor of n elements: the GELU between LayerNorm and Linear in
+ * CameraPoseEncoder.fc (pose_adaptor_ac3d.py:43-48). */
+int fw_activation(const uint16_t* x, uint16_t* out, int64_t n, int act, void* stream);
 
 #ifdef __cplusplus
 }

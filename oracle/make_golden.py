@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from fantasy_world_amd import config as fwc, synth   # noqa: E402
-from oracle import fw_oracle, fw_heads_oracle, ref_harness   # noqa: E402
+from oracle import fw_oracle, fw_heads_oracle, fw_pose_oracle, ref_harness   # noqa: E402
 
 CASES = {
     # name: (cfg kwargs, (f, h2, w2), timestep, text_len, uncond)
@@ -145,6 +145,34 @@ def main_pred(only):
     print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+# CameraPoseEncoder at the reference's real widths (6 -> 384 -> 768 -> 5120 -> 2560 -> 2048): name -> (frames, H, W)
+POSE_CASES = {
+    "pose_full_f9_32x48": (9, 32, 48),
+    "pose_full_f13_48x16": (13, 48, 16),
+}
+
+
+def main_pose(only):
+    ref_harness.install_stubs()
+    from FantasyWorld.diffsynth_wan21.models.pose_adaptor_ac3d import CameraPoseEncoder
+    for name, (f, H, Wd) in POSE_CASES.items():
+        if only and name not in only:
+            continue
+        W = synth.make_pose_encoder_weights()
+        enc = CameraPoseEncoder(context_dim=2048, dim=5120, patch_size=[1, 2, 2], in_channels=6, downscale_coef=8,
+                                pose_inject_method="adaln").eval()
+        enc.load_state_dict({k.replace("camera_condition.pose_encoder.", ""): v for k, v in W.items()}, strict=True)
+        pl = synth.make_plucker(f, H, Wd)
+        with torch.no_grad():
+            ref = enc(pl)
+        orc = fw_pose_oracle.camera_pose_encoder(W, pl)
+        print(f"[{name}] oracle vs reference plucker_fea rel-L2 = {rel(orc, ref):.3e}   shape {tuple(ref.shape)}")
+        path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+        torch.save({"plucker_fea": ref.float().contiguous(),
+                    "meta": dict(grid=(f, H, Wd), seed_weights=0, seed_plucker=5, torch=torch.__version__)}, path)
+        print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def main_heads(only):
     for name, (S, ph, pw) in HEAD_CASES.items():
         if only and name not in only:
@@ -182,3 +210,5 @@ if __name__ == "__main__":
         main_heads([a for a in args if a.startswith("heads")])
     if not args or any("_pred_" in a for a in args):
         main_pred([a for a in args if "_pred_" in a])
+    if not args or any(a.startswith("pose") for a in args):
+        main_pose([a for a in args if a.startswith("pose")])

@@ -199,17 +199,18 @@ class TorchRefOps:
         return self._r(x.clone())
 
     # ---- geometry heads: channels-last activations [T*H*W, C] ------------------------------------
-    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False):
+    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False, ph=None, pw=None):
         """Gather for a convolution as GEMM: x [T*H*W, C] -> [nt*Ho*Wo, kt*kh*kw*C] for output frames t0..t0+nt-1, column
-        ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][y*sh + dy - kh//2][x*sw + dx - kw//2][c], zero outside (causal
-        in time: vae_modified.py:17-36; 'same' padding in space)."""
+        ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][y*sh + dy - ph][x*sw + dx - pw][c], zero outside (causal in time:
+        vae_modified.py:17-36; spatial padding ph / pw, default k//2 = 'same')."""
         C = x.shape[1]
         nt = T - t0 if nt is None else nt
+        ph, pw = kh // 2 if ph is None else ph, kw // 2 if pw is None else pw
         v = x.to(torch.float32).view(T, H, W, C)
         if relu_in:
             v = F.relu(v)
-        v = F.pad(v, (0, 0, kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0))
-        Ho, Wo = (H + 2 * (kh // 2) - kh) // sh + 1, (W + 2 * (kw // 2) - kw) // sw + 1
+        v = F.pad(v, (0, 0, pw, pw, ph, ph, kt - 1, 0))
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         cols = []
         for dt in range(kt):
             for dy in range(kh):
@@ -265,3 +266,32 @@ class TorchRefOps:
         xyz, conf = y[:, :-1], y[:, -1]
         pts = torch.exp(xyz) if mode == "exp" else torch.sign(xyz) * torch.expm1(xyz.abs())
         return pts, 1 + conf.exp()
+
+    # ---- camera pose encoder -------------------------------------------------------------------------
+    def pixel_unshuffle_rows(self, x, r):
+        """x [F, H, W, C] -> [F*(H/r)*(W/r), C*r*r], column c*r*r + dy*r + dx (nn.PixelUnshuffle channel order)."""
+        Fr, H, W, C = x.shape
+        v = x.to(torch.float32).view(Fr, H // r, r, W // r, r, C).permute(0, 1, 3, 5, 2, 4)
+        return self._r(v.reshape(Fr * (H // r) * (W // r), C * r * r))
+
+    def group_norm_rows(self, x, frames, groups, w, b, eps=1e-5, relu=False):
+        """nn.GroupNorm(groups, C) on channels-last rows: statistics per (frame, group) over (C/groups) x pixels."""
+        rows, C = x.shape
+        v = x.to(torch.float32).view(frames, rows // frames, groups, C // groups)
+        mean = v.mean(dim=(1, 3), keepdim=True)
+        var = v.var(dim=(1, 3), unbiased=False, keepdim=True)
+        y = ((v - mean) * torch.rsqrt(var + eps)).view(rows, C) * w + b
+        return self._r(F.relu(y) if relu else y)
+
+    def time_avg_pool(self, x, frames, hw):
+        """CameraPoseEncoder.compress_time (pose_adaptor_ac3d.py:61-76) on [frames*hw, C] rows -> (rows, new frame count)."""
+        v = x.to(torch.float32).view(frames, hw, -1)
+        if frames % 2 == 1:
+            rest = v[1:]
+            out = torch.cat([v[:1], (rest[0::2] + rest[1::2]) * 0.5], dim=0) if frames > 1 else v
+        else:
+            out = (v[0:frames - 1:2] + v[1:frames:2]) * 0.5
+        return self._r(out.reshape(-1, v.shape[-1])), out.shape[0]
+
+    def activation(self, x, act):
+        return self._r(self._act(x.to(torch.float32), act))

@@ -111,3 +111,22 @@ class PredCase(Case):
 @pytest.fixture(scope="session")
 def case_pred():
     return PredCase("wan21_pred_l3_f2_8x12")
+
+
+class PoseCase:
+    """CameraPoseEncoder golden: real widths, weights and Pluecker embedding regenerated from seeds, the
+    reference module's plucker_fea from disk."""
+
+    def __init__(self, name):
+        from fantasy_world_amd import synth
+        self.name = name
+        self.golden = load_golden(name)
+        meta = self.golden["meta"]
+        self.grid = meta["grid"]
+        self.weights = synth.make_pose_encoder_weights(seed=meta["seed_weights"])
+        self.plucker = synth.make_plucker(*self.grid, seed=meta["seed_plucker"])
+
+
+@pytest.fixture(scope="session", params=["pose_full_f9_32x48", "pose_full_f13_48x16"])
+def pose_case(request):
+    return PoseCase(request.param)

@@ -109,3 +109,24 @@ def test_flash_attention_hook_b3():
     finally:
         undo()
     assert dit.flash_attention(q, k, v, 4).equal(want)
+
+
+def test_install_rebinds_pose_encoder(case_l2):
+    """CameraConditionModel.get_pose_fea (camera_control.py:233-234), the call generate_video makes before the loop
+    (model_wan21.py:271): same signature, same plucker_fea after install()."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install, uninstall, synth
+    W = dict(case_l2.weights)
+    W.update(synth.make_pose_encoder_weights())
+    model = ref_harness.build_reference_wan21(case_l2.cfg, weights=W)
+    pl = synth.make_plucker(9, 32, 48)
+    with torch.no_grad():
+        want = model.camera_condition.get_pose_fea(pl)
+    install(model, ops=TorchRefOps())
+    got = model.camera_condition.get_pose_fea(pl)
+    assert got.shape == want.shape and got.dtype == want.dtype and rel_l2(got, want) < 5e-6
+    assert model.camera_condition.get_pose_fea(None) is None
+    uninstall(model)
+    with torch.no_grad():
+        assert torch.equal(model.camera_condition.get_pose_fea(pl), want)

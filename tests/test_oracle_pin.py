@@ -84,3 +84,19 @@ def test_heads_oracle_full_width_golden(heads_case_full):
     for k in PRED_KEYS:
         assert rel_l2(pred[k], c.golden[k]) < 5e-6, k
         assert rel_l2(got[k], c.golden[k]) < 2e-5, k
+
+
+def test_pose_encoder_oracle_and_host_logic_match_reference_golden(pose_case):
+    """CameraPoseEncoder (A21): oracle/fw_pose_oracle.py and fantasy_world_amd.pose_encoder (on the torch ops) reproduce the
+    plucker_fea of the real module (pose_adaptor_ac3d.py:83-118) at its real widths."""
+    from fantasy_world_amd.pose_encoder import PoseEncoder
+    from oracle import fw_pose_oracle, ref_ops
+    c = pose_case
+    want = c.golden["plucker_fea"]
+    got = fw_pose_oracle.camera_pose_encoder(c.weights, c.plucker)
+    assert got.shape == want.shape and rel_l2(got, want) < 5e-6
+    host = PoseEncoder(c.weights.__getitem__, ref_ops.TorchRefOps()).encode(c.plucker)
+    assert host.shape == want.shape and rel_l2(host, want) < 5e-6
+    # with bf16 rounding where the HIP path stores bf16: the yardstick for the GPU tolerance
+    emu = PoseEncoder(c.weights.__getitem__, ref_ops.TorchRefOps(emulate_bf16=True)).encode(c.plucker)
+    assert rel_l2(emu, want) < 1.5e-2

@@ -1,0 +1,107 @@
+"""-m gpu: CameraPoseEncoder through libfw_mi355x.so.
+
+  * its kernels against the torch statement of the same op (oracle/ref_ops.py): PixelUnshuffle and the (1,2,2) patch gather
+    are bit-exact, GroupNorm / temporal pooling / GELU within one bf16 rounding (4e-3 rel-L2);
+  * plucker_fea of fantasy_world_amd.pose_encoder on HipOps against the golden output of the REAL reference module at its real
+    widths.  Tolerance 1.2e-2 rel-L2: bf16 is stored between the 1x1 convolutions, the three GroupNorms and the two
+    LayerNorms, the same host code on the torch ops with that rounding emulated measures 5.9e-3;
+  * the full-size input of BASELINE config 2 (81 x 480 x 832): shape, finiteness and the LayerNorm property of the output rows.
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1.2e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from fantasy_world_amd.hip_ops import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_ops import TorchRefOps
+    return TorchRefOps()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pixel_unshuffle_is_exact(ops, ref, dtype):
+    x = rnd(3, 16, 24, 6, seed=1)
+    want = ref.pixel_unshuffle_rows(x, 8)
+    got = ops.pixel_unshuffle_rows(x.to(dtype).cuda(), 8)
+    assert got.shape == want.shape and torch.equal(got.float().cpu(), want)
+    # the order is nn.PixelUnshuffle's
+    pu = torch.nn.functional.pixel_unshuffle(x.permute(0, 3, 1, 2), 8).permute(0, 2, 3, 1).reshape(want.shape)
+    assert torch.equal(want, pu)
+
+
+def test_patch_gather_without_padding_is_exact(ops, ref):
+    T, H, W, C = 3, 6, 8, 64
+    x = rnd(T * H * W, C, seed=2)
+    want = ref.im2col(x, T, H, W, 1, 2, 2, sh=2, sw=2, ph=0, pw=0)
+    got = ops.im2col(x.to(torch.bfloat16).cuda(), T, H, W, 1, 2, 2, sh=2, sw=2, ph=0, pw=0)
+    assert got.shape == (T * 3 * 4, 4 * C) and torch.equal(got.float().cpu(), want)
+
+
+@pytest.mark.parametrize("frames,hw,C,relu", [(5, 24, 384, False), (3, 7, 768, True), (1, 1000, 128, True)])
+def test_group_norm_rows(ops, ref, frames, hw, C, relu):
+    x = rnd(frames * hw, C, seed=3, scale=2.0) + 0.5
+    w, b = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    want = ref.group_norm_rows(x, frames, 2, w, b, relu=relu)
+    got = ops.group_norm_rows(x.to(torch.bfloat16).cuda(), frames, 2, w.cuda(), b.cuda(), relu=relu)
+    assert rel_l2(got.float(), want) < 4e-3
+
+
+@pytest.mark.parametrize("frames", [1, 2, 5, 8, 9])
+def test_time_avg_pool(ops, ref, frames):
+    hw, C = 11, 64
+    x = rnd(frames * hw, C, seed=6)
+    want, fw = ref.time_avg_pool(x, frames, hw)
+    got, fg = ops.time_avg_pool(x.to(torch.bfloat16).cuda(), frames, hw)
+    assert fg == fw and got.shape == want.shape and rel_l2(got.float(), want) < 4e-3
+
+
+def test_activation(ops, ref):
+    x = rnd(77, 128, seed=7, scale=2.0)
+    for act in ("gelu_erf", "relu", "silu"):
+        assert rel_l2(ops.activation(x.to(torch.bfloat16).cuda(), act).float(), ref.activation(x, act)) < 4e-3
+
+
+def test_pose_encoder_matches_reference_golden(pose_case, ops):
+    from fantasy_world_amd.pose_encoder import PoseEncoder
+    c = pose_case
+    enc = PoseEncoder(c.weights.__getitem__, ops)
+    got = enc.encode(c.plucker.cuda())
+    torch.cuda.synchronize()
+    want = c.golden["plucker_fea"]
+    assert got.shape == want.shape and got.dtype == torch.float32
+    err = rel_l2(got, want)
+    print(c.name, f"{err:.2e}")
+    assert err < POSE_TOL
+    got16 = enc.encode(c.plucker.cuda().bfloat16())             # the inference scripts hand over bf16
+    assert got16.dtype == torch.bfloat16 and rel_l2(got16.float(), want) < POSE_TOL
+
+
+def test_pose_encoder_full_size(ops):
+    """81 x 480 x 832 (BASELINE config 2) -> [1, 32760, 2048]; every output row went through LayerNorm(2048)."""
+    from fantasy_world_amd import synth
+    from fantasy_world_amd.pose_encoder import PoseEncoder
+    W = synth.make_pose_encoder_weights(device="cuda")
+    enc = PoseEncoder(W.__getitem__, ops)
+    pl = synth.make_plucker(81, 480, 832, device="cuda").bfloat16()
+    out = enc.encode(pl)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 21 * 30 * 52, 2048) and torch.isfinite(out.float()).all()
+    g, b = W["camera_condition.pose_encoder.fc.4.weight"], W["camera_condition.pose_encoder.fc.4.bias"]
+    z = (out[0].float() - b) / g
+    assert z.mean(dim=-1).abs().max() < 0.05 and (z.var(dim=-1, unbiased=False) - 1).abs().max() < 0.1
