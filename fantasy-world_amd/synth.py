@@ -323,3 +323,61 @@ def make_plucker(frames, H, W, channels=6, seed=5, device="cpu"):
     """Synthetic Pluecker embedding [1, frames, H, W, 6] (unit-scale ray moments / directions), bf16-representable."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     return torch.randn(1, frames, H, W, channels, generator=g).to(torch.bfloat16).float().to(device)
+
+
+def vae_decoder_weight_spec(dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temporal_upsample=(True, True, False),
+                            pre=""):
+    """conv2 + Decoder3d parameters of VideoVAE_ (diffsynth_wan21/models/wan_video_vae.py:379-430, 492-517), names relative
+    to the VideoVAE_ module (`pipe.vae.model.` on the fusion model)."""
+    spec = OrderedDict()
+    dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+    _conv(spec, pre + "conv2", (z_dim, z_dim, 1, 1, 1))
+    d = pre + "decoder."
+    _conv(spec, d + "conv1", (dims[0], z_dim, 3, 3, 3))
+
+    def res(p, cin, cout):
+        spec[p + "residual.0.gamma"] = ((cin, 1, 1, 1), ("ones_normal", 0.1))
+        _conv(spec, p + "residual.2", (cout, cin, 3, 3, 3))
+        spec[p + "residual.3.gamma"] = ((cout, 1, 1, 1), ("ones_normal", 0.1))
+        _conv(spec, p + "residual.6", (cout, cout, 3, 3, 3))
+        if cin != cout:
+            _conv(spec, p + "shortcut", (cout, cin, 1, 1, 1))
+
+    res(d + "middle.0.", dims[0], dims[0])
+    spec[d + "middle.1.norm.gamma"] = ((dims[0], 1, 1), ("ones_normal", 0.1))
+    _conv(spec, d + "middle.1.to_qkv", (3 * dims[0], dims[0], 1, 1))
+    _conv(spec, d + "middle.1.proj", (dims[0], dims[0], 1, 1))              # zero-initialised in the reference: randomised here
+    res(d + "middle.2.", dims[0], dims[0])
+    idx = 0
+    out_dim = dims[0]
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(num_res_blocks + 1):
+            res(f"{d}upsamples.{idx}.", cin, cout)
+            cin = cout
+            idx += 1
+        if i != len(dim_mult) - 1:
+            p = f"{d}upsamples.{idx}."
+            _conv(spec, p + "resample.1", (cout // 2, cout, 3, 3))
+            if temporal_upsample[i]:
+                _conv(spec, p + "time_conv", (2 * cout, cout, 3, 1, 1))
+            idx += 1
+        out_dim = cout
+    spec[d + "head.0.gamma"] = ((out_dim, 1, 1, 1), ("ones_normal", 0.1))
+    _conv(spec, d + "head.2", (3, out_dim, 3, 3, 3))
+    return spec
+
+
+def make_vae_decoder_weights(device="cpu", seed=0, bf16_round=True, **kw):
+    out = OrderedDict()
+    for name, (shape, init) in vae_decoder_weight_spec(**kw).items():
+        t = make_param(name, shape, init, device=device, dtype=torch.float32, seed=seed)
+        out[name] = t.to(torch.bfloat16).to(torch.float32) if bf16_round else t
+    return out
+
+
+def make_latents(T, h, w, z_dim=16, seed=7, device="cpu"):
+    """Synthetic normalised latents [1, 16, T, h, w] (what the sampler hands to the VAE), bf16-representable."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(1, z_dim, T, h, w, generator=g).to(torch.bfloat16).float().to(device)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from fantasy_world_amd import config as fwc, synth   # noqa: E402
-from oracle import fw_oracle, fw_heads_oracle, fw_pose_oracle, ref_harness   # noqa: E402
+from oracle import fw_oracle, fw_heads_oracle, fw_pose_oracle, fw_vae_oracle, ref_harness   # noqa: E402
 
 CASES = {
     # name: (cfg kwargs, (f, h2, w2), timestep, text_len, uncond)
@@ -173,6 +173,36 @@ def main_pose(only):
         print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
 
 
+# Wan video VAE decoder at its real widths (73 M parameters): name -> latent grid (T, h, w)
+VAE_CASES = {
+    "vae_full_t3_4x6": (3, 4, 6),
+    "vae_full_t2_3x5": (2, 3, 5),
+}
+
+
+def main_vae(only):
+    ref_harness.install_stubs()
+    from FantasyWorld.diffsynth_wan21.models.wan_video_vae import VideoVAE_
+    for name, (T, h, w) in VAE_CASES.items():
+        if only and name not in only:
+            continue
+        W = synth.make_vae_decoder_weights()
+        m = VideoVAE_(z_dim=16).eval()
+        sd = m.state_dict()
+        sd.update(W)
+        m.load_state_dict(sd)
+        z = synth.make_latents(T, h, w)
+        scale = [torch.tensor(fw_vae_oracle.VAE_MEAN), 1.0 / torch.tensor(fw_vae_oracle.VAE_STD)]
+        with torch.no_grad():
+            ref = m.decode(z, scale)
+        orc = fw_vae_oracle.vae_decode(W, z)
+        print(f"[{name}] oracle vs reference video rel-L2 = {rel(orc, ref):.3e}   shape {tuple(ref.shape)}")
+        path = os.path.join(ROOT, "tests", "golden", name + ".pt")
+        torch.save({"video": ref.float().contiguous(),
+                    "meta": dict(grid=(T, h, w), seed_weights=0, seed_latents=7, torch=torch.__version__)}, path)
+        print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")
+
+
 def main_heads(only):
     for name, (S, ph, pw) in HEAD_CASES.items():
         if only and name not in only:
@@ -212,3 +242,5 @@ if __name__ == "__main__":
         main_pred([a for a in args if "_pred_" in a])
     if not args or any(a.startswith("pose") for a in args):
         main_pose([a for a in args if a.startswith("pose")])
+    if not args or any(a.startswith("vae") for a in args):
+        main_vae([a for a in args if a.startswith("vae")])

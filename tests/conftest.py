@@ -130,3 +130,22 @@ class PoseCase:
 @pytest.fixture(scope="session", params=["pose_full_f9_32x48", "pose_full_f13_48x16"])
 def pose_case(request):
     return PoseCase(request.param)
+
+
+class VaeCase:
+    """Wan VAE decoder golden: real widths, weights and latents regenerated from seeds, the reference's
+    VideoVAE_.decode output from disk."""
+
+    def __init__(self, name):
+        from fantasy_world_amd import synth
+        self.name = name
+        self.golden = load_golden(name)
+        meta = self.golden["meta"]
+        self.grid = meta["grid"]
+        self.weights = synth.make_vae_decoder_weights(seed=meta["seed_weights"])
+        self.latents = synth.make_latents(*self.grid, seed=meta["seed_latents"])
+
+
+@pytest.fixture(scope="session", params=["vae_full_t3_4x6", "vae_full_t2_3x5"])
+def vae_case(request):
+    return VaeCase(request.param)

@@ -100,3 +100,12 @@ def test_pose_encoder_oracle_and_host_logic_match_reference_golden(pose_case):
     # with bf16 rounding where the HIP path stores bf16: the yardstick for the GPU tolerance
     emu = PoseEncoder(c.weights.__getitem__, ref_ops.TorchRefOps(emulate_bf16=True)).encode(c.plucker)
     assert rel_l2(emu, want) < 1.5e-2
+
+
+def test_vae_decoder_oracle_matches_reference_golden(vae_case):
+    """oracle/fw_vae_oracle.py (whole-sequence causal convolutions) reproduces VideoVAE_.decode, which decodes frame by frame
+    through its convolution cache (wan_video_vae.py:552-575)."""
+    from oracle import fw_vae_oracle
+    got = fw_vae_oracle.vae_decode(vae_case.weights, vae_case.latents)
+    want = vae_case.golden["video"]
+    assert got.shape == want.shape and rel_l2(got, want) < 1e-5
