@@ -36,7 +36,7 @@ __device__ __forceinline__ u32x4_t relu8(u32x4_t v) {
 // zero outside the volume: causal in time, 'same' in space.  One work-item per (output row, tap, 8 channels).
 __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
                                                      int64_t ldo, int C8, int T, int H, int W, int Ho, int Wo, int kt, int kh,
-                                                     int kw, int sh, int sw, int ph, int pw, int t0, int64_t total, int relu_in) {
+                                                     int kw, int sh, int sw, int ph, int pw, int up, int t0, int64_t total, int relu_in) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const int c8 = (int)(gid % C8);
@@ -51,9 +51,11 @@ __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict_
     const int ti = t0 + tt + dt - (kt - 1);
     const int yi = yo * sh + dy - ph;
     const int xi = xo * sw + dx - pw;
+    // H, W are the sizes of the STORED map; with up = 2 the convolution sees its nearest-neighbour x2 up-sampling
+    // (nn.Upsample(scale_factor=2, mode="nearest-exact"): source index = destination index / 2), which is never materialised
     u32x4_t v = {0u, 0u, 0u, 0u};
-    if (ti >= 0 && ti < T && yi >= 0 && yi < H && xi >= 0 && xi < W) {
-        v = *(const u32x4_t*)(x + (((int64_t)ti * H + yi) * W + xi) * ldx + c8 * 8);
+    if (ti >= 0 && ti < T && yi >= 0 && yi < H * up && xi >= 0 && xi < W * up) {
+        v = *(const u32x4_t*)(x + (((int64_t)ti * H + yi / up) * W + xi / up) * ldx + c8 * 8);
         if (relu_in) v = relu8(v);
     }
     *(u32x4_t*)(out + r * ldo + ((int64_t)tap * C8 + c8) * 8) = v;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const uint16_t* __
 // vae_modified.py:39-54, 201-203).  One wave per row; padded channels are zero on input and stay zero (gamma padded with 0).
 __global__ __launch_bounds__(256) void chan_rmsnorm_silu_kernel(const uint16_t* __restrict__ x, int64_t ldx, uint16_t* __restrict__ out,
                                                                 int64_t ldo, int64_t rows, int C, float scale,
-                                                                const float* __restrict__ gamma) {
+                                                                const float* __restrict__ gamma, int silu) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -111,7 +113,10 @@ __global__ __launch_bounds__(256) void chan_rmsnorm_silu_kernel(const uint16_t* 
         float f[8];
         unpack8(*(const u32x4_t*)(src + c), f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = fw_silu(f[i] * inv * gamma[c + i]);
+        for (int i = 0; i < 8; ++i) {
+            const float y = f[i] * inv * gamma[c + i];
+            f[i] = silu ? fw_silu(y) : y;
+        }
         *(u32x4_t*)(dst + c) = pack8(f);
     }
 }
@@ -334,24 +339,53 @@ __global__ __launch_bounds__(256) void activation_kernel(const uint16_t* __restr
     *(u32x4_t*)(out + gid * 8) = pack8(v);
 }
 
+// Row softmax of an fp32 score matrix (the single 384-wide head of the VAE's AttentionBlock, wan_video_vae.py:262-268, is two
+// GEMMs around this): out[r][c] = exp((s[r][c] - max_r) * scale) / sum_r for c < cols, 0 for cols <= c < cols_pad, bf16.
+// One work-group per row: the row (<= a few ten thousand scores) is read twice, from L2 the second time.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, uint16_t* __restrict__ out,
+                                                           int64_t ldo, int cols, int cols_pad, float scale) {
+    __shared__ float red[4];
+    const float* src = s + (int64_t)blockIdx.x * lds_;
+    uint16_t* dst = out + (int64_t)blockIdx.x * ldo;
+    float m = -3.0e38f;
+    for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, src[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) sum += __expf((src[c] - m) * scale);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = threadIdx.x * 2; c < cols_pad; c += 512) {
+        const float a = c < cols ? __expf((src[c] - m) * scale) * inv : 0.f;
+        const float b = c + 1 < cols ? __expf((src[c + 1] - m) * scale) * inv : 0.f;
+        *(uint32_t*)(dst + c) = pack_bf16x2(a, b);
+    }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
 extern "C" int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh,
-                         int kw, int sh, int sw, int ph, int pw, int t0, int nt, int relu_in, void* stream) {
+                         int kw, int sh, int sw, int ph, int pw, int up, int t0, int nt, int relu_in, void* stream) {
     if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out)) {
         fw_set_error("fw_im2col: C, ldx, ldo must be multiples of 8 and the bases 16-byte aligned"); return FW_E_BADARG; }
-    if (kt < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || t0 < 0 || nt < 0 || t0 + nt > T ||
-        H + 2 * ph < kh || W + 2 * pw < kw) {
-        fw_set_error("fw_im2col: bad kernel / stride / padding / frame window"); return FW_E_BADARG; }
-    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    if (kt < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || up < 1 || t0 < 0 || nt < 0 || t0 + nt > T ||
+        H * up + 2 * ph < kh || W * up + 2 * pw < kw) {
+        fw_set_error("fw_im2col: bad kernel / stride / padding / up-sampling / frame window"); return FW_E_BADARG; }
+    const int Ho = (H * up + 2 * ph - kh) / sh + 1, Wo = (W * up + 2 * pw - kw) / sw + 1;
     const int64_t total = (int64_t)nt * Ho * Wo * kt * kh * kw * (C / 8);
     if (total <= 0) return 0;
     if ((total + 255) / 256 > 0x7fffffffLL) { fw_set_error("fw_im2col: grid too large, chunk the frames"); return FW_E_BADARG; }
     hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, C / 8, T, H, W,
-                       Ho, Wo, kt, kh, kw, sh, sw, ph, pw, t0, total, relu_in);
+                       Ho, Wo, kt, kh, kw, sh, sw, ph, pw, up, t0, total, relu_in);
     return (int)hipGetLastError();
 }
 
@@ -369,12 +403,12 @@ extern "C" int fw_resize_bilinear(const uint16_t* x, int64_t ldx, uint16_t* out,
 }
 
 extern "C" int fw_chan_rmsnorm_silu(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int64_t rows, int C, int c_true,
-                                    const float* gamma, void* stream) {
+                                    const float* gamma, int silu, void* stream) {
     if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out) || c_true <= 0 || c_true > C || !gamma) {
         fw_set_error("fw_chan_rmsnorm_silu: bad arguments"); return FW_E_BADARG; }
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(chan_rmsnorm_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
-                       rows, C, sqrtf((float)c_true), gamma);
+                       rows, C, sqrtf((float)c_true), gamma, silu);
     return (int)hipGetLastError();
 }
 
@@ -469,5 +503,14 @@ extern "C" int fw_activation(const uint16_t* x, uint16_t* out, int64_t n, int ac
     if ((n % 8) || !aligned16(x) || !aligned16(out)) { fw_set_error("fw_activation: n % 8 == 0 and 16-byte bases required"); return FW_E_BADARG; }
     if (n <= 0) return 0;
     hipLaunchKernelGGL(activation_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, out, n / 8, act);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_softmax_rows(const float* s, int64_t lds, uint16_t* out, int64_t ldo, int rows, int cols, int cols_pad, float scale,
+                               void* stream) {
+    if (!s || !out || cols < 1 || cols_pad < cols || (cols_pad % 2) || (ldo % 2) || (((uintptr_t)out) & 3)) {
+        fw_set_error("fw_softmax_rows: cols_pad >= cols, cols_pad and ldo even, 4-byte aligned output"); return FW_E_BADARG; }
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, lds, out, ldo, cols, cols_pad, scale);
     return (int)hipGetLastError();
 }

@@ -25,7 +25,7 @@ SYMBOLS = [
     "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_control_patchify", "fw_im2col3x3",
     "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
-    "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation",
+    "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
 ]
 
 _lib = None
@@ -63,13 +63,14 @@ def load_library(path: str = LIB_PATH):
         "fw_debug_attention_timestamps": [vp, i32],
         "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
-        "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+        "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+        "fw_softmax_rows": [vp, i64, vp, i64, i32, i32, i32, f32, vp],
         "fw_pixel_unshuffle": [vp, i32, vp, i64, i32, i32, i32, i32, i32, vp],
         "fw_group_norm_rows": [vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp],
         "fw_time_avg_pool": [vp, i64, vp, i64, i32, i32, i32, vp],
         "fw_activation": [vp, vp, i64, i32, vp],
         "fw_resize_bilinear": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp],
-        "fw_chan_rmsnorm_silu": [vp, i64, vp, i64, i64, i32, i32, vp, vp],
+        "fw_chan_rmsnorm_silu": [vp, i64, vp, i64, i64, i32, i32, vp, i32, vp],
         "fw_depth_to_space": [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
         "fw_add_table": [vp, i64, vp, i64, i32, i32, vp],
         "fw_unfold_time2": [vp, i64, vp, i64, i32, i32, i32, vp],
@@ -81,7 +82,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    if lib.fw_abi_version() != 4:
+    if lib.fw_abi_version() != 5:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -334,17 +335,24 @@ class HipOps:
     def _bf16_rows(self, x):
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0, (x.dtype, x.shape)
 
-    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False, ph=None, pw=None):
+    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False, ph=None, pw=None, up=1):
         """Gather of a convolution as GEMM (fw_im2col): [T*H*W, C] -> [nt*Ho*Wo, kt*kh*kw*C], tap-major columns."""
         self._bf16_rows(x)
         assert x.shape[0] == T * H * W
         nt = T - t0 if nt is None else nt
         ph, pw = kh // 2 if ph is None else ph, kw // 2 if pw is None else pw
         C = x.shape[1]
-        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        Ho, Wo = (H * up + 2 * ph - kh) // sh + 1, (W * up + 2 * pw - kw) // sw + 1
         out = torch.empty(nt * Ho * Wo, kt * kh * kw * C, dtype=torch.bfloat16, device=self.device)
         _check(self.lib.fw_im2col(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), C, T, H, W, kt, kh, kw, sh, sw,
-                                  ph, pw, t0, nt, int(relu_in), self._stream()), "fw_im2col")
+                                  ph, pw, up, t0, nt, int(relu_in), self._stream()), "fw_im2col")
+        return out
+
+    def softmax_rows(self, s, scale, cols_pad):
+        assert s.dtype == torch.float32 and s.dim() == 2 and s.stride(1) == 1 and cols_pad % 2 == 0
+        out = torch.empty(s.shape[0], cols_pad, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_softmax_rows(s.data_ptr(), s.stride(0), out.data_ptr(), out.stride(0), s.shape[0], s.shape[1], cols_pad,
+                                        float(scale), self._stream()), "fw_softmax_rows")
         return out
 
     # ---- camera pose encoder (SURVEY.md A21) ---------------------------------------------------------------------------
@@ -389,12 +397,12 @@ class HipOps:
                                            x.shape[1], self._stream()), "fw_resize_bilinear")
         return out
 
-    def chan_rmsnorm_silu(self, x, gamma, c_true):
+    def chan_rmsnorm_silu(self, x, gamma, c_true, silu=True):
         self._bf16_rows(x)
         assert gamma.dtype == torch.float32 and gamma.numel() == x.shape[1]
         out = torch.empty_like(x)
         _check(self.lib.fw_chan_rmsnorm_silu(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
-                                             int(c_true), gamma.data_ptr(), self._stream()), "fw_chan_rmsnorm_silu")
+                                             int(c_true), gamma.data_ptr(), int(silu), self._stream()), "fw_chan_rmsnorm_silu")
         return out
 
     def depth_to_space(self, y, N, h, w, k, C):

@@ -122,6 +122,33 @@ def install(model, ops=None, device=None, cache_step_invariants=True):
     return engine
 
 
+def install_vae(vae, ops=None, device=None):
+    """Rebind `vae.model.decode(z, scale)` of a reference WanVideoVAE (diffsynth_wan21/models/wan_video_vae.py:552-575, the call
+    `tiled_decode` / `single_decode` make per tile, :643-692, :752-755) to fantasy_world_amd.vae_decoder.  Tiling, blending and
+    the final clamp stay the reference's own code.  Returns an `undo()` callable; weights are packed on first use."""
+    if ops is None:
+        from .hip_ops import HipOps
+        ops = HipOps(device or "cuda")
+    inner = vae.model
+    state = {}
+
+    def decode(self, z, scale):
+        if "dec" not in state:
+            from .vae_decoder import VaeDecoder
+            dec = inner.decoder
+            state["dec"] = VaeDecoder(dict(inner.named_parameters()).__getitem__, ops, dim=dec.dim, z_dim=dec.z_dim,
+                                      dim_mult=tuple(dec.dim_mult), num_res_blocks=dec.num_res_blocks,
+                                      temporal_upsample=tuple(dec.temperal_upsample))
+        return state["dec"].decode(z.to(ops.device), scale)
+
+    original = inner.decode
+    inner.decode = types.MethodType(decode, inner)
+
+    def undo():
+        inner.decode = original
+    return undo
+
+
 def uninstall(model):
     if hasattr(model, "_fw_reference_joint_forward"):
         model.joint_forward = model._fw_reference_joint_forward

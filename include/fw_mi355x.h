@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 4
+#define FW_ABI_VERSION 5
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -217,10 +217,12 @@ int fw_im2col3x3(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int
  * (wan/modules/vae_modified.py:17-36; kernels (3,1,1) and (3,3,3)).  x [T*H*W][C] -> out rows (t - t0, yo, xo) for output
  * frames t0..t0+nt-1, column ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][yo*sh + dy - ph][xo*sw + dx - pw][c], zero
  * outside the volume (causal in time; ph / pw = k/2 gives 'same', 0 the patch embedding Conv3d(k = s = (1,2,2)) of
- * CameraPoseEncoder, pose_adaptor_ac3d.py:40-41).  relu_in applies ReLU to the gathered values.
+ * CameraPoseEncoder, pose_adaptor_ac3d.py:40-41).  relu_in applies ReLU to the gathered values.  up = 2: the convolution runs
+ * on the nearest-neighbour x2 up-sampling of x (Resample 'upsample2d/3d' of the Wan VAE, diffsynth_wan21/models/
+ * wan_video_vae.py:92-99: nn.Upsample(scale 2, 'nearest-exact') + Conv2d 3x3), gathered on the fly.
  */
 int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh, int kw,
-              int sh, int sw, int ph, int pw, int t0, int nt, int relu_in, void* stream);
+              int sh, int sw, int ph, int pw, int up, int t0, int nt, int relu_in, void* stream);
 
 /* F.interpolate(mode="bilinear", align_corners=True) (custom_interpolate, vggt/heads/dpt_head.py:538-566):
  * x [N*h*w][C] -> out [N*H*W][C]. */
@@ -228,9 +230,10 @@ int fw_resize_bilinear(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ld
                        void* stream);
 
 /* SiLU(RMS_norm(x)) over channels (ResidualBlock_Half, wan/modules/vae_modified.py:39-54, 201-203):
- * out = silu(x / max(|x|_2, 1e-12) * sqrt(c_true) * gamma[c]); channels [c_true, C) are padding (zero in, zero out). */
+ * out = silu(x / max(|x|_2, 1e-12) * sqrt(c_true) * gamma[c]); channels [c_true, C) are padding (zero in, zero out).
+ * silu = 0: the bare RMS_norm of the VAE's AttentionBlock (diffsynth_wan21/models/wan_video_vae.py:246,256). */
 int fw_chan_rmsnorm_silu(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int64_t rows, int C, int c_true,
-                         const float* gamma, void* stream);
+                         const float* gamma, int silu, void* stream);
 
 /* nn.ConvTranspose2d with kernel = stride = k (vggt/heads/dpt_head.py:68-81) after its GEMM:
  * y[(n, yy, xx)][(dy*k + dx)*C + c] -> out[(n, yy*k + dy, xx*k + dx)][c]. */
@@ -276,6 +279,12 @@ int fw_time_avg_pool(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo,
 /* out = act(x) (FW_ACT_*) on a contiguous bf16 tensor of n elements: the GELU between LayerNorm and Linear in
  * CameraPoseEncoder.fc (pose_adaptor_ac3d.py:43-48). */
 int fw_activation(const uint16_t* x, uint16_t* out, int64_t n, int act, void* stream);
+
+/* Row softmax for the Wan VAE's AttentionBlock (diffsynth_wan21/models/wan_video_vae.py:235-273: one head of width 384 over the
+ * h*w positions of a frame, outside the flash kernel's head sizes): out[r][c] = softmax_c(s[r][c] * scale) for c < cols, 0 for
+ * cols <= c < cols_pad; s fp32 (lds), out bf16 (ldo).  QK^T and PV around it are fw_gemm_bf16 calls. */
+int fw_softmax_rows(const float* s, int64_t lds, uint16_t* out, int64_t ldo, int rows, int cols, int cols_pad, float scale,
+                    void* stream);
 
 #ifdef __cplusplus
 }

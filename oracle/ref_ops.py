@@ -199,7 +199,7 @@ class TorchRefOps:
         return self._r(x.clone())
 
     # ---- geometry heads: channels-last activations [T*H*W, C] ------------------------------------
-    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False, ph=None, pw=None):
+    def im2col(self, x, T, H, W, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, relu_in=False, ph=None, pw=None, up=1):
         """Gather for a convolution as GEMM: x [T*H*W, C] -> [nt*Ho*Wo, kt*kh*kw*C] for output frames t0..t0+nt-1, column
         ((dt*kh + dy)*kw + dx)*C + c = x[t + dt - (kt-1)][y*sh + dy - ph][x*sw + dx - pw][c], zero outside (causal in time:
         vae_modified.py:17-36; spatial padding ph / pw, default k//2 = 'same')."""
@@ -207,6 +207,9 @@ class TorchRefOps:
         nt = T - t0 if nt is None else nt
         ph, pw = kh // 2 if ph is None else ph, kw // 2 if pw is None else pw
         v = x.to(torch.float32).view(T, H, W, C)
+        if up != 1:      # gather from the nearest-neighbour up-sampled map (nn.Upsample(scale 2, 'nearest-exact'): src = dst // 2)
+            v = v.repeat_interleave(up, dim=1).repeat_interleave(up, dim=2)
+            H, W = H * up, W * up
         if relu_in:
             v = F.relu(v)
         v = F.pad(v, (0, 0, pw, pw, ph, ph, kt - 1, 0))
@@ -225,11 +228,19 @@ class TorchRefOps:
         v = F.interpolate(v, size=(H, W), mode="bilinear", align_corners=True)
         return self._r(v.permute(0, 2, 3, 1).reshape(N * H * W, C))
 
-    def chan_rmsnorm_silu(self, x, gamma, c_true):
-        """SiLU(F.normalize(x, dim=channel) * sqrt(C) * gamma) (vae_modified.py:39-54, :201-203); padded channels are zero."""
+    def chan_rmsnorm_silu(self, x, gamma, c_true, silu=True):
+        """SiLU(F.normalize(x, dim=channel) * sqrt(C) * gamma) (vae_modified.py:39-54, :201-203); padded channels are zero.
+        silu=False: the bare RMS_norm of the VAE's AttentionBlock (wan_video_vae.py:246,256)."""
         v = x.to(torch.float32)
         y = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12) * (c_true ** 0.5) * gamma
-        return self._r(F.silu(y))
+        return self._r(F.silu(y) if silu else y)
+
+    def softmax_rows(self, s, scale, cols_pad):
+        """softmax(s * scale) over the columns of s fp32 [rows, cols] -> [rows, cols_pad] (zero beyond cols)."""
+        p = torch.softmax(s.to(torch.float32) * scale, dim=-1)
+        out = torch.zeros(s.shape[0], cols_pad, dtype=torch.float32, device=s.device)
+        out[:, :s.shape[1]] = p
+        return self._r(out)
 
     def depth_to_space(self, y, N, h, w, k, C):
         """[N*h*w, k*k*C] with column (dy*k + dx)*C + c -> [N*(h*k)*(w*k), C] (ConvTranspose2d with kernel = stride)."""

@@ -130,3 +130,29 @@ def test_install_rebinds_pose_encoder(case_l2):
     uninstall(model)
     with torch.no_grad():
         assert torch.equal(model.camera_condition.get_pose_fea(pl), want)
+
+
+def test_install_vae_keeps_reference_tiling():
+    """WanVideoVAE.decode(tiled=True) (wan_video_vae.py:643-692, 776-782) with `model.decode` rebound: the reference's own tiling,
+    mask blending and clamp run unchanged around the replaced per-tile decoder."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install_vae, synth
+    ref_harness.install_stubs()
+    from FantasyWorld.diffsynth_wan21.models.wan_video_vae import WanVideoVAE
+    vae = WanVideoVAE(z_dim=16)
+    sd = vae.model.state_dict()
+    sd.update(synth.make_vae_decoder_weights())
+    vae.model.load_state_dict(sd)
+    z = synth.make_latents(2, 6, 7)
+    kw = dict(device="cpu", tiled=True, tile_size=(4, 4), tile_stride=(2, 3))
+    with torch.no_grad():
+        want = vae.decode(z, **kw)
+        want1 = vae.decode(z, device="cpu", tiled=False)
+    undo = install_vae(vae, ops=TorchRefOps())
+    got = vae.decode(z, **kw)
+    got1 = vae.decode(z, device="cpu", tiled=False)
+    assert got.shape == want.shape == (1, 3, 5, 48, 56) and rel_l2(got, want) < 1e-5 and rel_l2(got1, want1) < 1e-5
+    undo()
+    with torch.no_grad():
+        assert torch.equal(vae.decode(z, device="cpu", tiled=False), want1)

@@ -109,3 +109,18 @@ def test_vae_decoder_oracle_matches_reference_golden(vae_case):
     got = fw_vae_oracle.vae_decode(vae_case.weights, vae_case.latents)
     want = vae_case.golden["video"]
     assert got.shape == want.shape and rel_l2(got, want) < 1e-5
+
+
+def test_vae_decoder_host_logic_matches_reference_golden(vae_case):
+    """fantasy_world_amd.vae_decoder on the torch ops: weight packing (16 -> 64 and 96 -> 128 channel padding, latent
+    un-normalisation folded into conv2), up-sampling folded into the gather, GEMM-based single-head attention, chunking."""
+    from fantasy_world_amd.vae_decoder import VaeDecoder
+    from oracle import ref_ops
+    c = vae_case
+    want = c.golden["video"]
+    got = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps()).decode(c.latents)
+    assert got.shape == want.shape and rel_l2(got, want) < 1e-5
+    tiny = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps(), max_col_bytes=1).decode(c.latents)
+    assert rel_l2(tiny, got) < 1e-5
+    emu = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps(emulate_bf16=True)).decode(c.latents)
+    assert rel_l2(emu, want) < 2e-2              # the yardstick behind the GPU tolerance
