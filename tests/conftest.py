@@ -13,6 +13,8 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    # the CPU-side checkers run many small fp32 ops: more than a handful of threads only spins (and the hosts differ widely)
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
 
 
 def rel_l2(a, b):
