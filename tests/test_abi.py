@@ -40,3 +40,39 @@ def test_product_does_not_import_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point validates its arguments before it touches the device: bad calls come back as FW_E_BADARG with a message
+    (error behaviour of the boundary, include/fw_mi355x.h), never as a crash -- checked here without a GPU."""
+    import ctypes
+    lib = hip_ops.load_library()
+    buf = (ctypes.c_uint16 * 4096)()
+    base = ctypes.addressof(buf)
+    base += (-base) % 16
+    p, odd = ctypes.c_void_p(base), ctypes.c_void_p(base + 2)
+
+    def bad(rc, needle):
+        assert rc != 0, needle
+        msg = lib.fw_last_error().decode()
+        assert needle in msg, (needle, msg)
+
+    # fw_im2col: C not a multiple of 8; frame window outside the volume; misaligned base
+    bad(lib.fw_im2col(p, 12, p, 108, 12, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 1, 0, 1, 0, None), "fw_im2col")
+    bad(lib.fw_im2col(p, 64, p, 576, 64, 2, 4, 4, 1, 3, 3, 1, 1, 1, 1, 1, 1, 2, 0, None), "fw_im2col")
+    bad(lib.fw_im2col(odd, 64, p, 576, 64, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 1, 0, 1, 0, None), "fw_im2col")
+    bad(lib.fw_resize_bilinear(p, 60, p, 60, 1, 2, 2, 4, 4, 60, None), "fw_resize_bilinear")
+    bad(lib.fw_chan_rmsnorm_silu(p, 64, p, 64, 4, 64, 100, p, 1, None), "fw_chan_rmsnorm_silu")        # c_true > C
+    bad(lib.fw_depth_to_space(p, 64, p, 64, 1, 2, 2, 0, 64, None), "fw_depth_to_space")               # k < 1
+    bad(lib.fw_add_table(p, 64, p, 10, 4, 64, None), "fw_add_table")                                    # rows % hw != 0
+    bad(lib.fw_unfold_time2(p, 60, p, 64, 1, 4, 60, None), "fw_unfold_time2")
+    bad(lib.fw_add_act(p, None, p, 12, 0, None), "fw_add_act")                                          # n % 8 != 0
+    bad(lib.fw_adaln_rows(None, p, p, 4, 64, ctypes.c_float(1e-6), None), "fw_adaln_rows")
+    bad(lib.fw_head_activation(p, 4, 1, 0, p, p, None), "fw_head_activation")                           # n < 2
+    bad(lib.fw_pixel_unshuffle(p, 7, p, 64, 1, 8, 8, 1, 8, None), "fw_pixel_unshuffle")                 # unknown dtype code
+    bad(lib.fw_group_norm_rows(p, 64, p, 64, 1, 4, 64, 3, p, p, ctypes.c_float(1e-5), 0, None), "fw_group_norm_rows")   # C % groups
+    bad(lib.fw_time_avg_pool(p, 64, p, 64, 0, 4, 64, None), "fw_time_avg_pool")
+    bad(lib.fw_activation(p, p, 12, 1, None), "fw_activation")
+    bad(lib.fw_softmax_rows(p, 16, p, 16, 2, 16, 8, ctypes.c_float(1.0), None), "fw_softmax_rows")      # cols_pad < cols
+    # empty problems are accepted and do nothing
+    assert lib.fw_add_act(p, None, p, 0, 0, None) == 0 and lib.fw_head_activation(p, 0, 4, 0, p, p, None) == 0
