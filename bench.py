@@ -101,6 +101,7 @@ def main():
     shard, rank, world, local = topo.shard, topo.rank, topo.world, topo.local
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local = int(os.environ.get("FW_BENCH_DEVICE", local))     # debugging aid: several ranks on one GPU (with FW_DIST_BACKEND=gloo)
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     ops = HipOps(dev)

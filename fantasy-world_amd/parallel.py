@@ -223,7 +223,9 @@ def init_topology(backend=None, cfg_parallel=True):
         return Topology(local=local)
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  FW_DIST_BACKEND=gloo: debugging aid for the CFG-parallel path only (several ranks sharing
+            # one GPU, where RCCL refuses); gloo's all-to-all on device tensors does not make progress, so no sequence shard with it
+            backend = os.environ.get("FW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
