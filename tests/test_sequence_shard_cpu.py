@@ -71,10 +71,11 @@ def _worker(rank, world, port, grid, outdir, wpath):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,grid", [(3, (4, 4, 12))])
+@pytest.mark.parametrize("world,grid", [(3, (4, 4, 12)), (4, (5, 4, 12))])
 def test_sequence_shard_matches_single_process(world, grid, tmp_path, shared_weights):
-    """world 3: 40 and 16 heads do not divide -> K/V all-gather fallback, uneven frame split (2,1,1); the head-exchange path
-    (world 2 inside a CFG group) is covered by test_cfg_parallel_denoise_step_matches_single_process.  Run as the LAST
+    """world 3: 40 and 16 heads do not divide -> K/V all-gather fallback, uneven frame split (2,1,1).  world 4 (the shard of an
+    8-GPU run): 10 DiT heads per rank exchanged in the groups (4, 6), 4 VGGT heads, 3 bicross heads, frames split (2,1,1,1) so the
+    all-to-all row splits are uneven.  (World 2 inside a CFG group: test_cfg_parallel_denoise_step_matches_single_process.)  Run as the LAST
     sampling step (return_prediction=True): the geometry heads see the gathered frames on every rank."""
     from fantasy_world_amd import synth
     from fantasy_world_amd.engine import FusionEngine
