@@ -196,3 +196,50 @@ def test_head_groups_and_column_window():
         send = [full[(0 if s == 0 else counts[0]):(counts[0] if s == 0 else None)].reshape(counts[s], parts, world, c)[:, :, :, a:b]
                 .permute(2, 0, 1, 3)[r] for s in range(world)]
         assert torch.equal(torch.cat(send, dim=0), want)
+
+
+def _topology_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from fantasy_world_amd.parallel import init_topology
+    topo = init_topology(backend="gloo")
+    sh = topo.shard
+    assert topo.cfg_groups == 2 and topo.cfg_rank == rank // 4 and sh.world == 4 and sh.rank == rank % 4
+    sh._setup(21, 6, 5)                                   # 21 frames over 4 ranks: (6, 5, 5, 5)
+    assert sh.frame_counts == [6, 5, 5, 5] and sum(sh.dit_counts) == 21 * 6
+    # head exchange round trip on this group's rows, in two head groups, with the uneven aggregator row counts
+    H, hd, parts = 8, 4, 3
+    counts = sh.agg_counts
+    g = torch.Generator().manual_seed(100 + topo.cfg_rank)
+    full = torch.randn(sum(counts), parts * H * hd, generator=g)
+    start = sum(counts[:sh.rank])
+    mine = full[start:start + counts[sh.rank]].contiguous()
+    hl = H // sh.world
+    back = []
+    for a, b in ((0, 1), (1, hl)):
+        got = sh.rows_to_heads_async(mine, parts, counts, (a * hd, b * hd)).wait()       # [all rows, parts, (b-a)*hd]
+        want = full.view(-1, parts, sh.world, hl * hd)[:, :, sh.rank, a * hd:b * hd]
+        assert torch.equal(got, want)
+        back.append(((a, b), sh.heads_to_rows_async(got[:, 0].contiguous(), counts)))   # send the q part home again
+    q_mine = mine[:, :H * hd].view(-1, sh.world, hl * hd)
+    for (a, b), pend in back:
+        assert torch.equal(pend.wait().view(-1, sh.world, (b - a) * hd), q_mine[:, :, a * hd:b * hd])
+    rows = sh.all_gather_rows(mine[:, :4].contiguous(), counts)
+    assert torch.equal(rows, full[:, :4])
+    # the two groups exchange their outputs once per step
+    out = torch.full((2, 3), float(topo.cfg_rank))
+    pos, neg = topo.gather_cfg(out)
+    assert float(pos[0, 0]) == 0.0 and float(neg[0, 0]) == 1.0
+    torch.save(topo.describe(), os.path.join(outdir, f"d_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_topology_collectives(tmp_path):
+    """The process layout of `bench.py --gpus 8`: 2 CFG groups x 4-way sequence shard.  Group creation, the grouped head exchange
+    and its inverse with uneven row counts, the row all-gather and the CFG all-gather, on small tensors over gloo."""
+    mp.spawn(_topology_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    d = torch.load(os.path.join(str(tmp_path), "d_0.pt"))
+    assert "CFG-parallel x2" in d and "x4" in d
