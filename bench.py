@@ -158,7 +158,9 @@ def main():
     value = args.steps / dt
     # dominant kernel: one hd-128 self-attention launch = 4 * Lq_local * L * D FLOP (QK^T + PV)
     # (sharded: L rows x 40/n heads per rank after the head exchange = the same FLOPs as L/n rows x 40 heads)
-    attn_flops = 4.0 * L * L * cfg.dim / topo.sp_world
+    # under a sequence shard a block's heads go through the kernel in groups (FusionEngine._head_groups): average per launch
+    n_groups = len(eng._head_groups(cfg.num_heads // topo.sp_world)) if shard is not None and shard.heads_divisible(cfg.num_heads) else 1
+    attn_flops = 4.0 * L * L * cfg.dim / topo.sp_world / n_groups
     achieved = attn_flops / (attn_ms * 1e-3) if attn_n else 0.0
     # HBM-side traffic of the dominant kernel: measured with rocprofv3 PMC counters in separate passes (FETCH_SIZE, WRITE_SIZE)
     # as MI355X_MICROARCH.md prescribes, recorded under profiles/ with provenance; bench.py only reports the stored measurement
@@ -181,12 +183,13 @@ def main():
                    "parallelism": topo.describe(),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
-        "roofline": {"bound": "mfma", "kernel": "attention_sp_kernel<128, 1> (DiT self-attention, one launch per block)",
+        "roofline": {"bound": "mfma", "kernel": "attention_sp_kernel<128, 1> (DiT self-attention, one launch per block"
+                               + ("" if n_groups == 1 else f", in {n_groups} head groups under the sequence shard") + ")",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
                      "flops_per_launch": attn_flops, "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json)",
-                     "algorithmic_bytes_per_launch": 4.0 * L * cfg.dim * 2 / topo.sp_world},
+                     "algorithmic_bytes_per_launch": 4.0 * L * cfg.dim * 2 / topo.sp_world / n_groups},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, step_flops)
