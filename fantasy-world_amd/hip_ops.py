@@ -26,6 +26,7 @@ SYMBOLS = [
     "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
+    "fw_fp8_quant_rows", "fw_gemm_fp8",
 ]
 
 _lib = None
@@ -65,6 +66,8 @@ def load_library(path: str = LIB_PATH):
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
         "fw_softmax_rows": [vp, i64, vp, i64, i32, i32, i32, f32, vp],
+        "fw_fp8_quant_rows": [vp, i64, vp, i64, vp, i32, i32, i32, vp],
+        "fw_gemm_fp8": [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp],
         "fw_pixel_unshuffle": [vp, i32, vp, i64, i32, i32, i32, i32, i32, vp],
         "fw_group_norm_rows": [vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp],
         "fw_time_avg_pool": [vp, i64, vp, i64, i32, i32, i32, vp],
@@ -82,7 +85,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    if lib.fw_abi_version() != 5:
+    if lib.fw_abi_version() != 6:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -458,6 +461,36 @@ class HipOps:
         _check(self.lib.fw_head_activation(y.data_ptr(), rows, n, self.HEAD_MODES[mode], pts.data_ptr(), conf.data_ptr(),
                                            self._stream()), "fw_head_activation")
         return pts, conf
+
+    # ---- fp8 linear (AutoWrappedLinear.fp8_linear, diffsynth_wan22/vram_management/layers.py:115-151) ----
+    def pack_linear_fp8(self, w, b):
+        """w [N, K] (K % 64 == 0) -> e4m3 bytes (raw cast, scale 1: layers.py:134,137); bias rounded to bf16 (layers.py:138)."""
+        assert w.shape[1] % 64 == 0, w.shape
+        wb = w.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+        wq = torch.empty(wb.shape, dtype=torch.uint8, device=self.device)
+        _check(self.lib.fw_fp8_quant_rows(wb.data_ptr(), wb.stride(0), wq.data_ptr(), wq.stride(0), None, wb.shape[0], wb.shape[1],
+                                          1, self._stream()), "fw_fp8_quant_rows")
+        bb = None if b is None else b.detach().to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous()
+        return Linear(wq, bb)
+
+    def quantize_fp8_rows(self, x):
+        """x bf16 [M, K] -> (e4m3 bytes [M, K], fp32 scale [M]): the per-row activation quantiser of fp8_linear."""
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0
+        q = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        scale = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_fp8_quant_rows(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), x.shape[0],
+                                          x.shape[1], 0, self._stream()), "fw_fp8_quant_rows")
+        return q, scale
+
+    def linear_fp8(self, x, lin, out_f32=False):
+        """fp8_linear(x, w, b): quantise the rows of x, e4m3 x e4m3 GEMM with fp32 accumulation, * scale_a + bias -> x.dtype."""
+        q, scale = self.quantize_fp8_rows(x)
+        M, K = x.shape
+        assert K == lin.K
+        out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
+        _check(self.lib.fw_gemm_fp8(q.data_ptr(), q.stride(0), lin.w.data_ptr(), lin.w.stride(0), scale.data_ptr(), _ptr(lin.b),
+                                    out.data_ptr(), out.stride(0), _dt(out), M, lin.N, K, self._stream()), "fw_gemm_fp8")
+        return out
 
     def cast_act(self, x):
         assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 5
+#define FW_ABI_VERSION 6
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -285,6 +285,22 @@ int fw_activation(const uint16_t* x, uint16_t* out, int64_t n, int act, void* st
  * cols <= c < cols_pad; s fp32 (lds), out bf16 (ldo).  QK^T and PV around it are fw_gemm_bf16 calls. */
 int fw_softmax_rows(const float* s, int64_t lds, uint16_t* out, int64_t ldo, int rows, int cols, int cols_pad, float scale,
                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * fp8 linear: AutoWrappedLinear.fp8_linear, FantasyWorld/diffsynth_wan22/vram_management/layers.py:115-151 --
+ * the only fp8 definition the reference has (OCP e4m3fn, gfx950's native fp8).
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* raw = 0: scale[m] = max(bf16(max_k |x[m][k]| / 448), 1); q[m][k] = e4m3(x[m][k] / (scale[m] + 1e-8))   (layers.py:126-136)
+ * raw = 1: q = e4m3(x), scale untouched                                                                  (weight cast, layers.py:137)
+ * x bf16 [M][K] (ldx), q bytes [M][K] (ldq), round-to-nearest-even. */
+int fw_fp8_quant_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int M, int K, int raw, void* stream);
+
+/* C[M][N] = (A[M][K] W[N][K]^T) * scale_a[m] + bias[n]  -- torch._scaled_mm(xq, wq^T, scale_a, 1, bias, out_dtype)
+ * (layers.py:141-148) on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation; A, W e4m3 bytes (K % 64 == 0), bias fp32 holding
+ * bf16-rounded values (or NULL), out_dtype FW_DT_BF16 / FW_DT_F32. */
+int fw_gemm_fp8(const uint8_t* A, int64_t lda, const uint8_t* W, int64_t ldw, const float* scale_a, const float* bias,
+                void* C, int64_t ldc, int out_dtype, int M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -306,3 +306,23 @@ class TorchRefOps:
 
     def activation(self, x, act):
         return self._r(self._act(x.to(torch.float32), act))
+
+    # ---- fp8 linear ----------------------------------------------------------------------------------------
+    def pack_linear_fp8(self, w, b):
+        wq = self.to_f32(w).to(torch.bfloat16).to(torch.float8_e4m3fn)               # raw cast (layers.py:137)
+        return _Lin(wq, None if b is None else self.to_f32(b).to(torch.bfloat16).to(torch.float32))
+
+    def quantize_fp8_rows(self, x):
+        """AutoWrappedLinear.fp8_linear lines 126-136 on bf16-representable x [M, K]: (e4m3 tensor, fp32 scale [M])."""
+        xb = x.to(torch.bfloat16)
+        x_max = torch.max(torch.abs(xb), dim=-1, keepdim=True).values
+        scale = torch.clamp(x_max / 448.0, min=1.0).float()
+        return (xb / (scale + 1e-8)).to(torch.float8_e4m3fn), scale.reshape(-1)
+
+    def linear_fp8(self, x, lin, out_f32=False):
+        """torch._scaled_mm(xq, wq^T, scale_a, 1, bias, out_dtype) by its definition: (xq @ wq^T) * scale_a + bias."""
+        q, scale = self.quantize_fp8_rows(x)
+        y = (q.float() @ lin.w.float().t()) * scale[:, None]
+        if lin.b is not None:
+            y = y + lin.b
+        return y if out_f32 else self._r(y)

@@ -1,0 +1,75 @@
+"""-m gpu: fp8 linear through libfw_mi355x.so against the torch statement of AutoWrappedLinear.fp8_linear
+(oracle/ref_ops.py; pinned against the reference's code in tests/test_fp8_cpu.py).
+
+Quantisation is integer work: the e4m3 bytes and the row scales must be BIT-EXACT (IEEE division, round-to-nearest-even, the
+clamp at 1, the row maximum rounded through bf16).  The products of e4m3 values are exact in fp32 and the CPU sum of them is
+exact for these sizes; v_mfma_f32_32x32x16_fp8_fp8 aligns the 16 products of an instruction to a common exponent before adding
+them, which measures 1e-5 rel-L2 / 3e-5 max against the exact result (tools/probes/dbg_fp8.py).  Tolerance: 1e-4 rel-L2 on an fp32
+output, one bf16 rounding (4e-3) on a bf16 output."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from fantasy_world_amd.hip_ops import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_ops import TorchRefOps
+    return TorchRefOps()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("M,K,amp", [(7, 64, 1.0), (130, 1024, 50.0), (33, 5120, 500.0), (64, 256, 1e-3)])
+def test_row_quantiser_is_bit_exact(ops, ref, M, K, amp):
+    x = rnd(M, K, seed=1, scale=amp)
+    x[0, :] = 0.0                              # an all-zero row: scale 1, zeros
+    x[1, 3] = 448.0 * 7                        # a row far above the e4m3 range
+    x[2] = x[2].clamp(-447.0, 447.0)           # a row just inside: scale stays 1
+    want_q, want_s = ref.quantize_fp8_rows(x)
+    got_q, got_s = ops.quantize_fp8_rows(x.to(torch.bfloat16).cuda())
+    assert torch.equal(got_s.cpu(), want_s), (got_s.cpu() - want_s).abs().max()
+    assert torch.equal(got_q.cpu(), want_q.view(torch.uint8)), (got_q.cpu() != want_q.view(torch.uint8)).sum()
+
+
+def test_weight_cast_is_bit_exact(ops, ref):
+    w = rnd(200, 256, seed=2, scale=256 ** -0.5)
+    w[0, :8] = torch.tensor([0.0, 1e-4, 2e-3, 0.0019, 0.0156, 447.0, -3.0, 0.3])        # below / at the subnormal range, near max
+    lin = ops.pack_linear_fp8(w, None)
+    want = ref.pack_linear_fp8(w, None)
+    assert torch.equal(lin.w.cpu(), want.w.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 64, 128), (300, 200, 256), (129, 130, 1024), (1000, 1152, 5120)])
+def test_fp8_linear_matches_torch_statement(ops, ref, M, N, K):
+    x, w, b = rnd(M, K, seed=3, scale=4.0), rnd(N, K, seed=4, scale=K ** -0.5), rnd(N, seed=5, scale=0.1)
+    x[0, 0] = 3000.0
+    want = ref.linear_fp8(x, ref.pack_linear_fp8(w, b), out_f32=True)
+    lin = ops.pack_linear_fp8(w, b)
+    got32 = ops.linear_fp8(x.to(torch.bfloat16).cuda(), lin, out_f32=True)
+    got16 = ops.linear_fp8(x.to(torch.bfloat16).cuda(), lin)
+    assert got32.shape == (M, N) and rel_l2(got32, want) < 1e-4
+    assert got16.dtype == torch.bfloat16 and rel_l2(got16.float(), want) < 4e-3
+
+
+def test_fp8_linear_against_bf16_linear(ops):
+    """What the option costs in accuracy: e4m3 activations and raw-cast weights against the bf16 GEMM on the same operands --
+    a few percent, the reference's own trade-off (no reference semantics exist beyond fp8_linear itself; stated, not tuned)."""
+    M, N, K = 512, 512, 2048
+    x, w = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=K ** -0.5)
+    a = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_linear(w, None), out_f32=True)
+    b = ops.linear_fp8(x.to(torch.bfloat16).cuda(), ops.pack_linear_fp8(w, None), out_f32=True)
+    err = rel_l2(b, a)
+    print(f"fp8 vs bf16 linear rel-L2 {err:.3e}")
+    assert err < 0.1
