@@ -26,6 +26,36 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN_DIR, name + ".pt"), map_location="cpu", weights_only=False)
 
 
+class BF16Weights(dict):
+    """name -> tensor, stored in bf16 (the synthetic weights are bf16-representable by construction, so this is exact) and handed
+    out as fp32.  Halves what the session-scoped cases keep resident: several 1 B-parameter dictionaries plus the spawned gloo
+    ranks would not fit the build container's memory otherwise."""
+
+    def __init__(self, src=()):
+        super().__init__()
+        self.update(src)
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v.detach().to(torch.bfloat16) if v.dtype == torch.float32 else v)
+
+    def update(self, other=()):
+        for k, v in (other.items() if hasattr(other, "items") else other):
+            self[k] = v
+
+    def __getitem__(self, k):
+        v = super().__getitem__(k)
+        return v.to(torch.float32) if v.dtype == torch.bfloat16 else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return ((k, self[k]) for k in self.keys())
+
+    def values(self):
+        return (self[k] for k in self.keys())
+
+
 class Case:
     """One golden case: config, synthetic weights and inputs regenerated from seeds, reference outputs from disk."""
 
@@ -38,7 +68,7 @@ class Case:
         f, h2, w2 = meta["grid"]
         self.grid = (f, h2, w2)
         self.uncond = meta["uncond"]
-        self.weights = synth.make_weights(self.cfg, seed=meta["seed_weights"])
+        self.weights = BF16Weights(synth.make_weights(self.cfg, seed=meta["seed_weights"]))
         self.inputs = synth.make_inputs(self.cfg, f, h2, w2, seed=meta["seed_inputs"], timestep=meta["timestep"],
                                         text_len=meta["text_len"])
 
@@ -81,7 +111,7 @@ class HeadsCase:
         meta = self.golden["meta"]
         self.hc = fwc.HeadsConfig() if meta.get("heads") == "full" else fwc.HeadsConfig.small()
         self.S, self.ph, self.pw = meta["grid"]
-        self.weights = synth.make_heads_weights(self.hc, seed=meta["seed_weights"])
+        self.weights = BF16Weights(synth.make_heads_weights(self.hc, seed=meta["seed_weights"]))
         self.output_list = synth.make_output_list(self.hc, self.S, self.ph, self.pw, seed=meta["seed_tokens"])
 
 
