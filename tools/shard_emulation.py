@@ -10,27 +10,31 @@ sys.path.insert(0, ROOT)
 from fantasy_world_amd import config as fwc, synth
 from fantasy_world_amd.engine import FusionEngine
 from fantasy_world_amd.hip_ops import HipOps
-from fantasy_world_amd.parallel import SequenceShard
+from fantasy_world_amd.parallel import Ready, SequenceShard
 
 
 class LocalShard(SequenceShard):
+    """SequenceShard whose collectives complete locally with tensors of the right shape (own data tiled)."""
+
     def _tile(self, t, counts):
         total = sum(counts)
         reps = (total + t.shape[0] - 1) // t.shape[0]
         return t.repeat(reps, *([1] * (t.dim() - 1)))[:total].contiguous()
 
-    def all_gather_rows(self, t, counts):
-        return self._tile(t.contiguous(), counts)
+    def all_gather_rows_async(self, t, counts):
+        return Ready(self._tile(t.contiguous(), counts))
 
-    def rows_to_heads(self, t, parts, counts):
+    def rows_to_heads_async(self, t, parts, counts, cols=None):
         rows, width = t.shape
         c = width // (parts * self.world)
-        mine = t.reshape(rows, parts, self.world, c)[:, :, self.rank, :].contiguous()
-        return self._tile(mine, counts)
+        mine = t.reshape(rows, parts, self.world, c)[:, :, self.rank, :]
+        if cols is not None:
+            mine = mine[:, :, cols[0]:cols[1]]
+        return Ready(self._tile(mine.contiguous(), counts))
 
-    def heads_to_rows(self, o, counts):
+    def heads_to_rows_async(self, o, counts):
         rows = counts[self.rank]
-        return o[:rows].repeat(1, self.world).contiguous()
+        return Ready(o[:rows].repeat(1, self.world).contiguous())
 
 
 def main():
