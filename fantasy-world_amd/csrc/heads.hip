@@ -121,6 +121,38 @@ __global__ __launch_bounds__(256) void chan_rmsnorm_silu_kernel(const uint16_t* 
     }
 }
 
+// Same, for narrow maps (C = 64 / 128 / 256, e.g. the 96 -> 128-channel full-resolution level of the VAE decoder): a row only
+// fills C/8 lanes, so one wave takes 64 / (C/8) rows and reduces inside each lane group.
+template <int LPR>
+__global__ __launch_bounds__(256) void chan_rmsnorm_silu_narrow_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                       uint16_t* __restrict__ out, int64_t ldo, int64_t rows,
+                                                                       float scale, const float* __restrict__ gamma, int silu) {
+    constexpr int RPW = 64 / LPR;                        // rows per wave
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int c = (lane % LPR) * 8;
+    const bool live = row < rows;
+    float f[8];
+    if (live) unpack8(*(const u32x4_t*)(x + row * ldx + c), f);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = 0.f;
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (!live) return;
+    const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float y = f[i] * inv * gamma[c + i];
+        f[i] = silu ? fw_silu(y) : y;
+    }
+    *(u32x4_t*)(out + row * ldo + c) = pack8(f);
+}
+
 // ConvTranspose2d with kernel = stride = k after its GEMM: y[(n, yy, xx)][(dy*k + dx)*C + c] -> out[(n, yy*k + dy, xx*k + dx)][c]
 __global__ __launch_bounds__(256) void depth_to_space_kernel(const uint16_t* __restrict__ y, int64_t ldy, uint16_t* __restrict__ out,
                                                              int64_t ldo, int C8, int h, int w, int k, int64_t total) {
@@ -407,8 +439,18 @@ extern "C" int fw_chan_rmsnorm_silu(const uint16_t* x, int64_t ldx, uint16_t* ou
     if (C <= 0 || (C % 8) || (ldx % 8) || (ldo % 8) || !aligned16(x) || !aligned16(out) || c_true <= 0 || c_true > C || !gamma) {
         fw_set_error("fw_chan_rmsnorm_silu: bad arguments"); return FW_E_BADARG; }
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(chan_rmsnorm_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
-                       rows, C, sqrtf((float)c_true), gamma, silu);
+    hipStream_t st = (hipStream_t)stream;
+    const float sc = sqrtf((float)c_true);
+    if (C == 64 || C == 128 || C == 256) {
+        const int lpr = C / 8, rpb = 4 * (64 / lpr);     // rows per 256-thread block
+        const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+        if (C == 64) hipLaunchKernelGGL(chan_rmsnorm_silu_narrow_kernel<8>, dim3(grid), dim3(256), 0, st, x, ldx, out, ldo, rows, sc, gamma, silu);
+        else if (C == 128) hipLaunchKernelGGL(chan_rmsnorm_silu_narrow_kernel<16>, dim3(grid), dim3(256), 0, st, x, ldx, out, ldo, rows, sc, gamma, silu);
+        else hipLaunchKernelGGL(chan_rmsnorm_silu_narrow_kernel<32>, dim3(grid), dim3(256), 0, st, x, ldx, out, ldo, rows, sc, gamma, silu);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(chan_rmsnorm_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, out, ldo,
+                       rows, C, sc, gamma, silu);
     return (int)hipGetLastError();
 }
 

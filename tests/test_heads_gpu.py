@@ -80,8 +80,9 @@ def test_resize_bilinear_align_corners(ops, ref, N, h, w, H, W, C):
     assert rel_l2(got.float(), want) < 4e-3
 
 
-def test_chan_rmsnorm_silu(ops, ref):
-    rows, C, c_true = 301, 128, 96
+@pytest.mark.parametrize("rows,C,c_true", [(301, 128, 96), (77, 64, 64), (1030, 256, 192), (50, 384, 384), (9, 1024, 1024)])
+def test_chan_rmsnorm_silu(ops, ref, rows, C, c_true):
+    """Both kernels: several rows per wave for C = 64 / 128 / 256, one wave per row otherwise; ragged row counts."""
     x = rnd(rows, C, seed=6, scale=3.0)
     x[:, c_true:] = 0
     g = torch.zeros(C)
