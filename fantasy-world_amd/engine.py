@@ -145,7 +145,6 @@ class FusionEngine:
             self.ctl_conv = lin(ca + "conv.weight", ca + "conv.bias")                                   # [D, 24*64*4]
             self.ctl_res1 = lin(ca + "residual_blocks.0.conv1.weight", ca + "residual_blocks.0.conv1.bias")   # [D, 9*D]
             self.ctl_res2 = lin(ca + "residual_blocks.0.conv2.weight", ca + "residual_blocks.0.conv2.bias")
-            self._ctl_cache = None
         self.head_mod = ops.to_f32(g(pd + "head.modulation").reshape(2, cfg.dim))
         self.head = lin(pd + "head.head.weight", pd + "head.head.bias")
         self.dit = [self._pack_dit(b, g, lin, lin_cat) for b in range(cfg.num_layers)]
@@ -462,17 +461,17 @@ class FusionEngine:
         """Wan2.2 control adapter (wan_video_camera_controller.py:24-44,64-76): PixelUnshuffle(8) -> Conv2d(k2,s2) ->
         ResidualBlock(conv3x3 -> ReLU -> conv3x3, + skip), as three GEMMs over gathered patches.  fp32 [L, D], added to the
         patch embedding (wan_video_dit.py:390-396).  The input is constant over the whole generation (and identical for the
-        positive and negative pass), the reference recomputes it in every call (31 TFLOP at 480p); here it is cached on the
-        identity of the tensor."""
+        positive and negative pass), the reference recomputes it in every call (31 TFLOP at 480p); with the step-invariant cache
+        enabled it is computed once per control tensor (cache off = recomputed per call, like the reference)."""
         ops = self.ops
-        key = (ctl.data_ptr(), tuple(ctl.shape), ctl._version, str(ctl.device))
-        if self._ctl_cache is not None and self._ctl_cache[0] == key:
-            return self._ctl_cache[1]
-        c0 = ops.linear(ops.control_patchify(ctl), self.ctl_conv, out_f32=True)                     # conv k2 s2
-        t1 = ops.linear(ops.im2col3x3(ops.cast_act(c0), F, h, w), self.ctl_res1, act="relu")        # conv1 + ReLU
-        out = ops.linear(ops.im2col3x3(t1, F, h, w), self.ctl_res2, res=c0, out_f32=True)           # conv2 + skip
-        self._ctl_cache = (key, out)
-        return out
+
+        def compute():
+            c0 = ops.linear(ops.control_patchify(ctl), self.ctl_conv, out_f32=True)                     # conv k2 s2
+            t1 = ops.linear(ops.im2col3x3(ops.cast_act(c0), F, h, w), self.ctl_res1, act="relu")        # conv1 + ReLU
+            return ops.linear(ops.im2col3x3(t1, F, h, w), self.ctl_res2, res=c0, out_f32=True)          # conv2 + skip
+
+        # the entry holds a reference to `ctl`, so its storage cannot be recycled under the same address by the next generation
+        return self.invariants.get("control_features", (ctl,), compute)
 
     @torch.no_grad()
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
@@ -498,6 +497,8 @@ class FusionEngine:
         tabs = self._get_tables(F, h, w)
         if sh is not None:
             tabs = sh.localize_tables(tabs, F, hw, cfg.n_special)
+        # tests: collect["per_block"] = fn(kind, index, stream) is called with the fp32 streams after every block
+        per_block = None if collect is None else collect.get("per_block")
 
         # ---- A1: time embeddings, fp32 (wan_video_dit.py:393-399, vggt.py:126-130) ----------------------------
         sin = ops.sinusoid(timestep, cfg.freq_dim)
@@ -539,6 +540,8 @@ class FusionEngine:
             blk = self.dit[b]
             mod = self._dit_attn(blk, xs, ctx_txt, ctx_img, t_mod, tabs, plucker)
             self._dit_ffn(blk, xs, mod)
+            if per_block is not None:
+                per_block("x", b, xs)
         if collect is not None:
             collect["x_after_pcb"] = xs.clone()
 
@@ -575,9 +578,12 @@ class FusionEngine:
             mod = self._dit_attn_end(sd, ctx_txt, ctx_img, plucker)             # VGGT output exchange behind DiT cross-attn
             e = self._vggt_attn_end(sg)
             if i in cfg.cross_attention_list and not uncond:
-                self._bicross(self.bicross[i], xs, tok, tabs)
+                self._bicross(self.bicross[cfg.cross_attention_list.index(i)], xs, tok, tabs)
             self._dit_ffn(blk, xs, mod)
             self._vggt_mlp(gb, tok, e)
+            if per_block is not None:
+                per_block("x", cfg.start_index + i, xs)
+                per_block("tok", i, tok)
             if i in need:
                 outputs[i] = torch.cat([frame_out.view(1, S_loc, P, -1), tok.view(1, S_loc, P, -1)], dim=-1)
         if collect is not None:
@@ -613,8 +619,10 @@ class FusionEngine:
         return torch.stack([self.special[1], self.special[1]], dim=0).contiguous()
 
     def _plucker_all_zero(self, plucker_fea):
-        key = (plucker_fea.data_ptr(), tuple(plucker_fea.shape), plucker_fea._version)
-        if self._plucker_zero_cache is None or self._plucker_zero_cache[0] != key:
-            # one host sync per NEW plucker tensor (the reference syncs 25x per forward, camera_control.py:111)
-            self._plucker_zero_cache = (key, bool((plucker_fea == 0).all().item()))
-        return self._plucker_zero_cache[1]
+        """camera_control.py:111 (`plucker_fea.abs().sum() == 0` -> adapter skipped).  One host sync per NEW plucker tensor (the
+        reference syncs 25x per forward); the verdict is remembered TOGETHER WITH the tensor, so a different tensor that the
+        caching allocator places at the same address later (next generation) can never inherit it."""
+        c = self._plucker_zero_cache
+        if c is None or c[0] is not plucker_fea or c[1] != plucker_fea._version:
+            self._plucker_zero_cache = c = (plucker_fea, plucker_fea._version, bool((plucker_fea == 0).all().item()))
+        return c[2]

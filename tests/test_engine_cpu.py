@@ -50,23 +50,74 @@ def test_all_zero_plucker_skips_adapter(case_l2):
 
 
 def test_wan22_control_features_are_cached_per_tensor(case_w22):
-    """The control adapter output depends only on control_camera_latents_input: computed once, reused for the negative pass
-    and the following steps, recomputed when the tensor changes (in place or a new one)."""
+    """The control adapter output depends only on control_camera_latents_input: with the step-invariant cache it is computed
+    once, reused for the negative pass and the following steps, recomputed when the tensor changes (in place or a new one);
+    with the cache off it is recomputed in every call, like the reference (wan_video_dit.py:390-396)."""
     case = case_w22
-    eng = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps())
     ins = case.inputs
     kw = forward_kwargs(case)
+
+    class CountingOps(TorchRefOps):
+        n_ctl = 0
+
+        def control_patchify(self, *a, **k):
+            self.n_ctl += 1
+            return super().control_patchify(*a, **k)
+
+    ops = CountingOps()
+    eng = FusionEngine(case.cfg, case.weights.__getitem__, ops, cache_step_invariants=True)
     a, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
-    cached = eng._ctl_cache[1]
     b, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context_neg"], **kw)
-    assert eng._ctl_cache[1] is cached
+    assert ops.n_ctl == 1
     kw2 = dict(kw, control_camera_latents_input=kw["control_camera_latents_input"] * 2.0)
     c, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw2)
-    assert eng._ctl_cache[1] is not cached and not torch.equal(a, c)
+    assert ops.n_ctl == 2 and not torch.equal(a, c)
     kw["control_camera_latents_input"].mul_(2.0)                      # in-place edit bumps the version counter
     d, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
-    assert torch.equal(c, d)
+    assert ops.n_ctl == 3 and torch.equal(c, d)
     kw["control_camera_latents_input"].mul_(0.5)
+    plain_ops = CountingOps()
+    plain = FusionEngine(case.cfg, case.weights.__getitem__, plain_ops)
+    e, _ = plain.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+    f, _ = plain.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+    assert plain_ops.n_ctl == 2 and torch.equal(e, a) and torch.equal(f, a)
+
+
+def test_caches_survive_address_recycling_between_generations(case_w22, case_l2):
+    """a cache keyed on (address, shape, version) alone serves stale data when the allocator hands the next
+    generation's conditioning tensor the address of the previous one.  The caches hold the source tensor itself: a second
+    generation whose control / Pluecker tensor is a DIFFERENT object (even one that would compare equal by address after the
+    first was freed) is recomputed, and the all-zero verdict of one Pluecker tensor is never applied to another."""
+    import gc
+    case = case_w22
+    ins = case.inputs
+    eng = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps(), cache_step_invariants=True)
+    plain = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps())
+    kw = forward_kwargs(case)
+    ctl1 = kw["control_camera_latents_input"].clone()
+    a, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **dict(kw, control_camera_latents_input=ctl1))
+    ptr, shape = ctl1.data_ptr(), ctl1.shape
+    del ctl1
+    gc.collect()
+    # the cache still references the first tensor, so the allocator cannot give its storage to the next one
+    ctl2 = torch.empty(shape).copy_(kw["control_camera_latents_input"] * -1.5)
+    assert ctl2.data_ptr() != ptr
+    b, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **dict(kw, control_camera_latents_input=ctl2))
+    want, _ = plain.joint_forward(ins["x"], ins["timestep"], ins["context"], **dict(kw, control_camera_latents_input=ctl2))
+    assert torch.equal(b, want) and not torch.equal(a, b)
+    # Pluecker all-zero verdict (Wan2.1): zero tensor first, then a non-zero one of the same shape / version
+    c = case_l2
+    e2 = FusionEngine(c.cfg, c.weights.__getitem__, TorchRefOps(), cache_step_invariants=True)
+    p2 = FusionEngine(c.cfg, c.weights.__getitem__, TorchRefOps())
+    k2 = forward_kwargs(c)
+    z = torch.zeros_like(k2["plucker_fea"])
+    e2.joint_forward(c.inputs["x"], c.inputs["timestep"], c.inputs["context"], **dict(k2, plucker_fea=z))
+    del z
+    gc.collect()
+    nz = k2["plucker_fea"].clone()
+    got, _ = e2.joint_forward(c.inputs["x"], c.inputs["timestep"], c.inputs["context"], **dict(k2, plucker_fea=nz))
+    want, _ = p2.joint_forward(c.inputs["x"], c.inputs["timestep"], c.inputs["context"], **dict(k2, plucker_fea=nz))
+    assert torch.equal(got, want)
 
 
 def test_engine_return_prediction_matches_reference_golden(case_pred):
