@@ -1,8 +1,7 @@
-"""Import shim: `import fantasy_world_amd` -> the package that lives in ../fantasy-world_amd/ (hyphenated dir)."""
-import os as _os
+"""fantasy_world_amd: MI355X-native (gfx950) execution of FantasyWorld's per-step denoising forward
+(Fantasy-AMAP/fantasy-world, FantasyWorldFusionModel.joint_forward) behind the reference's own call surface."""
+from .config import FWConfig, HeadsConfig, wan21_14b, wan22_a14b, plumbing, plumbing22  # noqa: F401
+from .install import install, uninstall, install_flash_attention, install_vae  # noqa: F401
 
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "fantasy-world_amd")
-__path__ = [_real]
-__file__ = _os.path.join(_real, "__init__.py")
-with open(__file__) as _f:
-    exec(compile(_f.read(), __file__, "exec"))
+__all__ = ["FWConfig", "HeadsConfig", "wan21_14b", "wan22_a14b", "plumbing", "plumbing22", "install", "uninstall",
+           "install_flash_attention", "install_vae"]

@@ -78,8 +78,16 @@ def sdpa(q, k, v, num_heads):
     qh = q.view(b, lq, num_heads, -1).transpose(1, 2)
     kh = k.view(b, lk, num_heads, -1).transpose(1, 2)
     vh = v.view(b, lk, num_heads, -1).transpose(1, 2)
-    s = qh @ kh.transpose(-1, -2) / math.sqrt(qh.shape[-1])
-    o = torch.softmax(s, dim=-1) @ vh
+    if b * num_heads * lq * lk <= (1 << 28):
+        s = qh @ kh.transpose(-1, -2) / math.sqrt(qh.shape[-1])
+        o = torch.softmax(s, dim=-1) @ vh
+    else:   # same arithmetic, one head and <= 8192 query rows at a time (the full score tensor would not fit the host memory)
+        o = torch.empty_like(qh)
+        for bi in range(b):
+            for hh in range(num_heads):
+                for r0 in range(0, lq, 8192):
+                    sc = qh[bi, hh, r0:r0 + 8192] @ kh[bi, hh].transpose(-1, -2) / math.sqrt(qh.shape[-1])
+                    o[bi, hh, r0:r0 + 8192] = torch.softmax(sc, dim=-1) @ vh[bi, hh]
     return o.transpose(1, 2).reshape(b, lq, -1)
 
 
@@ -274,10 +282,13 @@ def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluck
     freqs_bi_dit = expand_freqs(fb, f, h, w)
     freqs_bi_agg = build_freqs_3d_with_extra_cis(fb, f, h, w, cfg.n_special)
 
+    per_block = None if collect is None else collect.get("per_block")     # fn(kind, index, stream) after every block
     for b in range(cfg.start_index):
         p = cfg.dit_prefix(b)
         x, mods = dit_block_partial(x, ctx, t_mod, freqs, W, p, cfg, cfg.has_adapter(b), plucker_fea)
         x = dit_block_remaining(x, mods, W, p, cfg)
+        if per_block is not None:
+            per_block("x", b, x[0])
     if collect is not None:
         collect["x_after_pcb"] = x[0].clone()
 
@@ -318,6 +329,9 @@ def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluck
         x = dit_block_remaining(x, mods, W, p, cfg)
         tg = vggt_block_remaining(tg, e_g, W, gp, cfg)
         tokens = tg.reshape(f, P, -1)
+        if per_block is not None:
+            per_block("x", cfg.start_index + i, x[0])
+            per_block("tok", i, tokens.reshape(f * P, -1))
         if collect is not None and "output_list" in collect:
             # model_wan21.py:208-212: frame | global intermediates of every layer, concatenated on channels -> [f, P, 2C]
             collect["output_list"][i] = torch.cat([frame_out, tokens], dim=-1)

@@ -4,7 +4,7 @@ Used in the build container (where /root/reference is mounted) to
   (1) pin oracle/fw_oracle.py (the CPU restatement) against the reference's own modules, and
   (2) generate the golden fixtures under tests/golden/ (see oracle/make_golden.py).
 It cannot travel to the GPU box (no /root/reference there); nothing in the product path
-(fantasy-world_amd/) may import it.
+(fantasy_world_amd/) may import it.
 
 What it does:
   * registers permissive stub modules for the non-hot-path imports the container lacks

@@ -89,6 +89,62 @@ def case_w22():
     return Case("wan22_l2_f2_8x12")
 
 
+@pytest.fixture(scope="session")
+def case_cfg1():
+    """BASELINE.json configs[0]: 2-block model on latents [1,16,9,64,64] (L = 9216, L2 = 9261); noise_pred in full, the streams
+    as 64 sampled rows (golden["rows_dit"], golden["rows_agg"])."""
+    return Case("wan21_cfg1_l2_f9_64x64")
+
+
+@pytest.fixture(scope="session")
+def case_depth():
+    """4 PCB + 4 IRG blocks on 96 tokens with the streams after EVERY block (24 sampled rows each)."""
+    return Case("wan21_depth_l8_s4_f2_12x16")
+
+
+class ParityLog:
+    """Measured errors of the run, written to gpurun_out/parity_<gpu|cpu>.json at session end (copied to profiles/rNN/parity.json):
+    every assert that goes through check() records (measured, bound), so a regression inside the bound is still visible."""
+
+    def __init__(self):
+        self.rows = {}
+
+    def check(self, name, value, bound):
+        self.rows[name] = {"measured": float(value), "bound": float(bound)}
+        assert value < bound, f"{name}: {value:.3e} >= {bound:.3e}"
+        return value
+
+    def note(self, name, value):
+        self.rows[name] = value
+
+
+PARITY = ParityLog()
+
+
+@pytest.fixture(scope="session")
+def parity():
+    return PARITY
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY.rows:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    kind = "gpu" if torch.cuda.is_available() else "cpu"
+    path = os.path.join(out, f"parity_{kind}.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old.update(PARITY.rows)
+    with open(path, "w") as f:
+        json.dump(old, f, indent=1, sort_keys=True)
+
+
 def forward_kwargs(case, dev=None):
     """joint_forward keyword arguments of a case (both flavours), optionally moved to a device."""
     ins = case.inputs

@@ -33,8 +33,8 @@ def test_no_cpu_fallback():
 
 
 def test_product_does_not_import_oracle():
-    """Nothing under fantasy-world_amd/ may import oracle/ (the oracle is test infrastructure)."""
-    pkg = os.path.join(ROOT, "fantasy-world_amd")
+    """Nothing under fantasy_world_amd/ may import oracle/ (the oracle is test infrastructure)."""
+    pkg = os.path.join(ROOT, "fantasy_world_amd")
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
             if fn.endswith(".py"):

@@ -36,6 +36,27 @@ def test_engine_bf16_emulation_yardstick(case_l2):
     assert err < 1e-2, err
 
 
+def test_engine_depth_yardstick(case_depth, parity):
+    """The 8-block depth golden on the engine's host logic: fp32 op set = the reference after every block; with activations
+    rounded to bf16 where the HIP path stores bf16 = the yardstick the GPU's per-block errors are read against."""
+    case, g = case_depth, case_depth.golden
+    for emulate in (False, True):
+        eng = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps(emulate_bf16=emulate))
+        got = {"x": {}, "tok": {}}
+        col = {"per_block": lambda kind, i, t: got[kind].__setitem__(i, t[g["rows_dit"] if kind == "x" else g["rows_agg"]].clone())}
+        out, _ = eng.joint_forward(case.inputs["x"], case.inputs["timestep"], case.inputs["context"], collect=col,
+                                   **forward_kwargs(case))
+        ex = [rel_l2(got["x"][b], g["x_blocks"][b]) for b in range(case.cfg.num_layers)]
+        et = [rel_l2(got["tok"][j], g["tok_blocks"][j]) for j in range(case.cfg.n_irg)]
+        if emulate:
+            parity.note("depth/yardstick_bf16_emulation_x_per_block", ex)
+            parity.note("depth/yardstick_bf16_emulation_vggt_per_block", et)
+            parity.note("depth/yardstick_bf16_emulation_noise_pred", rel_l2(out, g["noise_pred"]))
+            assert max(ex) < 1.6e-2 and max(et) < 1.6e-2, (ex, et)
+        else:
+            assert max(ex) < 2e-5 and max(et) < 2e-5 and rel_l2(out, g["noise_pred"]) < 2e-5, (ex, et)
+
+
 def test_all_zero_plucker_skips_adapter(case_l2):
     """camera_control.py:111,124-127: an all-zero plucker feature leaves the attention output untouched."""
     case = case_l2

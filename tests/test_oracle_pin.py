@@ -21,6 +21,31 @@ def test_oracle_matches_reference_golden(case_name, request):
         assert err < 5e-6, f"{case.name}:{k} oracle deviates from the reference golden: rel-L2 {err:.3e}"
 
 
+@pytest.mark.parametrize("case_name", ["case_depth", "case_cfg1"])
+def test_oracle_matches_reference_golden_at_depth_and_size(case_name, request):
+    """The 8-block depth golden (streams after every block) and BASELINE config 1 (L = 9216; sampled rows): outputs of the
+    real reference, reproduced by the oracle."""
+    case = request.getfixturevalue(case_name)
+    ins, g = case.inputs, case.golden
+    col = {}
+    if "x_blocks" in g:
+        got = {"x": {}, "tok": {}}
+        col["per_block"] = lambda kind, i, t: got[kind].__setitem__(i, t.reshape(-1, t.shape[-1]).clone())
+    out = fw_oracle.joint_forward(case.weights, case.cfg, ins["x"], ins["timestep"], ins["context"],
+                                  ins["clip_feature"], ins["y"], ins["plucker_fea"], ins["plucker_context_lens"], collect=col)
+    assert rel_l2(out, g["noise_pred"]) < 5e-6
+    rd, ra = g["rows_dit"], g["rows_agg"]
+    L2 = col["tokens_final"].shape[0]
+    assert rel_l2(col["x_after_pcb"][rd], g["x_after_pcb"]) < 5e-6
+    assert rel_l2(col["x_final"][rd], g["x_final"]) < 5e-6
+    assert rel_l2(col["tokens_final"].reshape(L2, -1)[ra], g["tokens_final"]) < 5e-6
+    if "x_blocks" in g:
+        for b in range(case.cfg.num_layers):
+            assert rel_l2(got["x"][b][rd], g["x_blocks"][b]) < 5e-6, b
+        for j in range(case.cfg.n_irg):
+            assert rel_l2(got["tok"][j][ra], g["tok_blocks"][j]) < 5e-6, j
+
+
 def test_heads_oracle_matches_reference_golden(heads_case):
     """oracle/fw_heads_oracle.py reproduces the prediction dict of the real VGGT._head_predction (vggt.py:134-154)."""
     from conftest import PRED_KEYS

@@ -1,7 +1,7 @@
 import sys, torch
 sys.path.insert(0, '.')
 import importlib
-hip_ops = importlib.import_module('fantasy-world_amd.hip_ops')
+hip_ops = importlib.import_module('fantasy_world_amd.hip_ops')
 ops = hip_ops.HipOps('cuda:0')
 torch.manual_seed(0)
 def run(heads, hd, Lq, Lk):
