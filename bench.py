@@ -1,39 +1,82 @@
 #!/usr/bin/env python
 """denoise-steps/sec of FantasyWorld's joint_forward hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py                                  # N = 1, BASELINE configs[1], finishes in a few minutes
+    python bench.py --gpus 8 --steps 20 --warmup 5   # self-launches 8 ranks (one per GPU) under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W       # the same, launched by the driver
 
-Workload: BASELINE.json configs[1] -- Wan2.1-I2V-14B-480P + IRG fusion + VGGT geometry branch, 81 frames x 480 x 832
-(latents [1,16,21,60,104], L = 32760 DiT tokens, L2 = 32865 VGGT tokens), random weights of the real architecture
-(40 DiT blocks, 24+24 VGGT blocks, 24 bicross blocks, 25 camera adapters), synthetic inputs.  One step = 2
-joint_forward calls (CFG positive + negative, return_prediction=False) + CFG combine + flow-match Euler update
-(FantasyWorld/fusion/model_wan21.py:289-322).  N > 1 (fantasy_world_amd/parallel.py): the two CFG forwards go to two rank
-groups, each group sequence-shards its forward (head all-to-all for attention), i.e. strong scaling of one sample.
+Headline workload (default): BASELINE.json configs[1] -- Wan2.1-I2V-14B-480P + IRG fusion + VGGT geometry branch, 81 frames x
+480 x 832 (latents [1,16,21,60,104], L = 32760 DiT tokens, L2 = 32865 VGGT tokens), random weights of the real architecture (40
+DiT blocks, 24+24 VGGT blocks, 24 bicross blocks, 25 camera adapters), synthetic inputs.  One step = 2 joint_forward calls (CFG
+positive + negative, return_prediction=False) + CFG combine + flow-match Euler update (FantasyWorld/fusion/model_wan21.py:289-322).
+Other workloads (never the headline; `config.workload` names them):
+    --model wan22 --height 720 --width 1280     BASELINE configs[3]: Wan2.2-Fun-A14B-Control-Camera, both experts resident,
+                                                expert chosen per step (inference_wan22.py:229-277)
+    --precision fp8                             BASELINE configs[4]'s arithmetic: the DiT / VGGT linears through the fp8 linear
+                                                (diffsynth_wan22/vram_management/layers.py:115-151); `dtype` says "fp8_e4m3"
+    --cache-invariants                          step-invariant intermediates cached; off = the
+                                                reference's per-step work
+N > 1 (fantasy_world_amd/parallel.py): the two CFG forwards go to two rank groups, each group sequence-shards its forward (head
+all-to-all for attention) -- strong scaling of ONE sample; the JSON line then carries a `comm` block (bytes each GPU sends per
+step, time the compute stream spent blocked on exchanges).
 
-Prints ONE JSON line on rank 0 (see README / task contract) with `roofline` for the dominant kernel (the hd-128
-self-attention launch, 41% of the forward's FLOPs) and, at N = 1, `cpu_baseline`.
+Prints ONE JSON line on rank 0 with `roofline` for the dominant kernel (the hd-128 self-attention launch, 41% of the forward's
+FLOPs), `kernels` (live HIP-event averages of the other big launches) and, at N = 1, `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from fantasy_world_amd import config as fwc, synth                      # noqa: E402
-from fantasy_world_amd.engine import FusionEngine                       # noqa: E402
-from fantasy_world_amd.hip_ops import HipOps                            # noqa: E402
-from fantasy_world_amd.parallel import init_topology                    # noqa: E402
-from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step  # noqa: E402
-
 MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
+MFMA_FP8_PEAK = 5.0e15       # dense fp8 MFMA peak, same table
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", choices=["wan21", "wan22"], default="wan21")
+    ap.add_argument("--frames", type=int, default=81)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=832)
+    ap.add_argument("--layers", type=int, default=40, help="debug only: anything but 40 is not a BASELINE workload")
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16")
+    ap.add_argument("--cache-invariants", action="store_true")
+    ap.add_argument("--experts", type=int, default=None, help="wan22: resident experts (default 2; 1 = high-noise only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="bound on the CPU baseline sample")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / topology / collective check without a GPU: no engine, no metric (value = null)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks (one per GPU) under torch.distributed.run on
+    127.0.0.1 and pass rank 0's JSON line through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def forward_flops(cfg, L, L2, S, P, Lc, Li):
@@ -46,70 +89,80 @@ def forward_flops(cfg, L, L2, S, P, Lc, Li):
     macs += 2 * n_irg * L2 * (4 * C * C + 2 * C * Cm) + n_irg * 2 * S * P * P * C + n_irg * 2 * L2 * L2 * C
     macs += n_bi * (L * 3 * D * Bd + L2 * 3 * C * Bd + 4 * L * L2 * Bd)
     macs += L * 144 * D + Lc * (cfg.text_dim * D + D * D) + Li * (1280 * 1280 + 1280 * D) + L * D * C + L * D * 64
+    if cfg.control_adapter:
+        macs += L * 6144 * D + 2 * 9 * L * D * D
     return 2.0 * macs
 
 
-def cpu_baseline(cfg, step_flops):
-    """Oracle ("port") timed on this box's host cores on a bounded sample: one full-width DiT block (self-attention +
-    cross-attention + camera adapter + FFN, fp32, PyTorch CPU kernels) at a reduced token count, converted to
-    denoise-steps/s through its algorithmic FLOP count (the full fp32 model is 64 GB and ~6600 s/step)."""
-    from oracle import fw_oracle
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    Ls, Lc, Li = 3072, 512, cfg.clip_tokens
-    one = fwc.FWConfig(num_layers=1, start_index=1, cross_attention_list=[])
-    W = {}
-    spec = synth.weight_spec(one)
-    p = one.dit_prefix(0)
-    for name, (shape, init) in spec.items():
-        if name.startswith(p):
-            W[name] = synth.make_param(name, shape, init)
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(1, Ls, cfg.dim, generator=g)
-    ctx = torch.randn(1, Li + Lc, cfg.dim, generator=g)
-    t_mod = torch.randn(1, 6, cfg.dim, generator=g)
-    pl = torch.randn(1, Ls, cfg.plucker_dim, generator=g)
-    hd = cfg.dim // cfg.num_heads
-    freqs = fw_oracle.expand_freqs(fw_oracle.precompute_freqs_cis_3d(hd), 3, 32, 32)
-    D, Fd = cfg.dim, cfg.ffn_dim
-    macs = (4 * Ls * D * D + 2 * Ls * Ls * D + 2 * Ls * D * D + 2 * (Lc + Li) * D * D + 2 * Ls * (Lc + Li) * D + 2 * Ls * D * Fd
-            + Ls * (2048 * 2048 + D * 1024 + 1024 * 2048 + 2048 * 409 + 409 * D))
+def dry_run(args):
+    """No GPU: rendezvous (gloo), CFG groups, every collective of the sequence shard on small CPU tensors, barrier +
+    max-over-ranks timing, the JSON line.  Proves the launcher and the topology code; measures nothing."""
+    import torch
+    import torch.distributed as dist
+    from fantasy_world_amd import parallel
+    topo = parallel.init_topology(backend="gloo")
+    stats = parallel.enable_comm_stats()
+    sh = topo.shard
+    F, hw, heads, hd = 8, 6, 8, 4
     t0 = time.time()
-    with torch.no_grad():
-        y, mods = fw_oracle.dit_block_partial(x, ctx, t_mod, freqs, W, p, one, True, pl)
-        y = fw_oracle.dit_block_remaining(y, mods, W, p, one)
-    dt = time.time() - t0
-    eff = 2.0 * macs / dt
-    return {"value": eff / step_flops, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle DiT block (self+cross+adapter+FFN, fp32) at {Ls} tokens: {dt:.1f} s, "
-                      f"{eff / 1e12:.3f} TFLOP/s effective, extrapolated by algorithmic FLOPs to the 81x480x832 step"}
+    for _ in range(args.warmup + args.steps):
+        if sh is not None:
+            sh.localize_tables(dict(dit=torch.zeros(F * hw, 2), bi_dit=torch.zeros(F * hw, 2), bi_agg=torch.zeros(F * (5 + hw), 2)),
+                               F, hw, 5)
+            rows = sh.dit_counts[sh.rank]
+            qkv = torch.randn(rows, 3 * heads * hd)
+            if sh.heads_divisible(heads):
+                got = sh.rows_to_heads_async(qkv, 3, sh.dit_counts).wait()
+                back = sh.heads_to_rows_async(got[:, 0].contiguous(), sh.dit_counts).wait()
+                assert torch.equal(back, qkv[:, :heads * hd])            # exchange and its inverse are an identity on q
+            full = sh.all_gather_rows(qkv, sh.dit_counts)
+            assert full.shape[0] == F * hw
+        if topo.cfg_groups == 2:
+            pos, neg = topo.gather_cfg(torch.full((4,), float(topo.cfg_rank)))
+            assert float(pos[0]) == 0.0 and float(neg[0]) == 1.0
+    if topo.world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.time() - t0], dtype=torch.float64)
+    if topo.world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if topo.rank == 0:
+        print(json.dumps({"metric": "denoise-steps/sec (DRY RUN: launcher / topology / collectives only, no engine)",
+                          "value": None, "unit": "denoise-steps/s", "n_gpus": topo.world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "wall_s": float(tt.item()),
+                          "config": {"workload": "dry run", "parallelism": topo.describe()},
+                          "comm": stats.summary(args.warmup + args.steps)}), flush=True)
+    if topo.world > 1:
+        dist.destroy_process_group()
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=81)
-    ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--width", type=int, default=832)
-    ap.add_argument("--layers", type=int, default=40, help="debug only: anything but 40 is not the BASELINE workload")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.dry_run:
+        return dry_run(args)
 
-    topo = init_topology()
+    import torch
+    from fantasy_world_amd import config as fwc, synth, parallel
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step, denoise_step_dual
+
+    topo = parallel.init_topology()
     shard, rank, world, local = topo.shard, topo.rank, topo.world, topo.local
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("FW_BENCH_DEVICE", local))     # debugging aid: several ranks on one GPU (with FW_DIST_BACKEND=gloo)
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     ops = HipOps(dev)
+    stats = parallel.enable_comm_stats() if world > 1 else None
 
-    cfg = fwc.wan21_14b()
+    wan22 = args.model == "wan22"
+    cfg = fwc.wan22_a14b() if wan22 else fwc.wan21_14b()
     if args.layers != 40:
-        cfg = fwc.FWConfig(num_layers=args.layers, start_index=min(16, args.layers - 1),
-                           cross_attention_list=list(range(args.layers - min(16, args.layers - 1))))
+        si = min(16, args.layers - 1)
+        cfg = (fwc.plumbing22 if wan22 else fwc.plumbing)(num_layers=args.layers, start_index=si)
     F = (args.frames - 1) // 4 + 1
     H2, W2 = args.height // 8, args.width // 8
     hw = (H2 // 2) * (W2 // 2)
@@ -117,70 +170,132 @@ def main():
     L2 = F * P
 
     spec = synth.weight_spec(cfg)
+    n_experts = (args.experts or 2) if wan22 else 1
     t0 = time.time()
-    eng = FusionEngine(cfg, lambda n: synth.make_param(n, spec[n][0], spec[n][1], device=dev), ops, shard=shard)
+    engines = [FusionEngine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s), ops, shard=shard,
+                            cache_step_invariants=args.cache_invariants, precision=args.precision) for s in range(n_experts)]
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    eng = engines[0]
 
     ins = synth.make_inputs(cfg, F, H2, W2, seed=1, device=dev, dtype=torch.bfloat16)
-    cond = dict(clip_feature=ins["clip_feature"], y=ins["y"], plucker_fea=ins["plucker_fea"],
-                plucker_context_lens=ins["plucker_context_lens"])
+    cond = dict(y=ins["y"])
+    if wan22:
+        cond["control_camera_latents_input"] = ins["control_camera_latents_input"]
+    else:
+        cond.update(clip_feature=ins["clip_feature"], plucker_fea=ins["plucker_fea"],
+                    plucker_context_lens=ins["plucker_context_lens"])
     sched = FlowMatchScheduler()
     sched.set_timesteps(50)
     latents = ins["x"]
+    # Wan2.2: high-noise expert above the boundary (inference_wan22.py:229-240; 0.9 * 1000 for the A14B pair)
+    boundary = 900.0
+
+    def one_step(step_id, latents):
+        if n_experts == 2:
+            return denoise_step_dual(engines[0], engines[1], boundary, sched, step_id, latents, ins["context"],
+                                     ins["context_neg"], cond, topo=topo)[0]
+        return denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo)[0]
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    sp = topo.sp_world
     step_id = 0
     for _ in range(args.warmup):
-        latents, _ = denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo)
+        latents = one_step(step_id, latents)
         step_id += 1
-    ops.start_kernel_timing("attn_hd128_self", lambda kw: kw["hd"] == 128 and kw["Lk"] >= L)
+    if stats is not None:
+        stats.records.clear()
+    ops.start_kernel_timing({
+        "attn_hd128_self": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] >= L,
+        "attn_hd128_cross": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] < 1024,
+        "attn_hd96_bicross_dit_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] >= L2,
+        "attn_hd96_bicross_vggt_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] < L2,
+        "attn_hd64_global": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["batch"] == 1,
+        "attn_hd64_frame": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["batch"] > 1,
+        "gemm_qkv": lambda i: i["kind"] == "linear" and i["N"] == 3 * cfg.dim and i["K"] == cfg.dim,
+        "gemm_ffn0": lambda i: i["kind"] == "linear" and i["N"] == cfg.ffn_dim,
+        "gemm_ffn2_gate_residual": lambda i: i["kind"] == "linear" and i["K"] == cfg.ffn_dim,
+        "gemm_o_gate_residual": lambda i: i["kind"] == "linear" and i["N"] == cfg.dim and i["K"] == cfg.dim and i["res"] and i["M"] > 1024,
+    })
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        latents, _ = denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo)
+        latents = one_step(step_id, latents)
         step_id += 1
     barrier()
     dt = time.time() - t0
-    attn_ms, attn_n = ops.stop_kernel_timing()
+    timed = ops.stop_kernel_timing()
+    comm = stats.summary(args.steps) if stats is not None else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(latents.float()).all(), "non-finite latents"
 
-    f_fwd = forward_flops(cfg, L, L2, F, P, 512, cfg.clip_tokens if cfg.has_image_input else 0)
+    Li = cfg.clip_tokens if cfg.has_image_input else 0
+    f_fwd = forward_flops(cfg, L, L2, F, P, 512, Li)
     step_flops = 2.0 * f_fwd
     value = args.steps / dt
+    peak = MFMA_FP8_PEAK if args.precision == "fp8" else MFMA_BF16_PEAK
     # dominant kernel: one hd-128 self-attention launch = 4 * Lq_local * L * D FLOP (QK^T + PV)
-    # (sharded: L rows x 40/n heads per rank after the head exchange = the same FLOPs as L/n rows x 40 heads)
-    # under a sequence shard a block's heads go through the kernel in groups (FusionEngine._head_groups): average per launch
-    n_groups = len(eng._head_groups(cfg.num_heads // topo.sp_world)) if shard is not None and shard.heads_divisible(cfg.num_heads) else 1
-    attn_flops = 4.0 * L * L * cfg.dim / topo.sp_world / n_groups
+    # (sharded: L rows x 40/n heads per rank after the head exchange = the same FLOPs as L/n rows x 40 heads; a block's heads
+    #  go through the kernel in groups under the shard (FusionEngine._head_groups): average per launch)
+    n_groups = len(eng._head_groups(cfg.num_heads // sp)) if shard is not None and shard.heads_divisible(cfg.num_heads) else 1
+    attn_flops = 4.0 * L * L * cfg.dim / sp / n_groups
+    attn_ms, attn_n = timed["attn_hd128_self"]
     achieved = attn_flops / (attn_ms * 1e-3) if attn_n else 0.0
+    Ll, L2l = L / sp, L2 / sp
+    kflops = {"attn_hd128_cross": None,      # two launches of different Lk (512 / 257) share the tag: reported as time only
+              "attn_hd96_bicross_dit_queries": 4.0 * Ll * L2 * cfg.bicross_dim,
+              "attn_hd96_bicross_vggt_queries": 4.0 * L2l * L * cfg.bicross_dim,
+              "attn_hd64_global": 4.0 * L2 * L2 * cfg.vggt_dim / sp,
+              "attn_hd64_frame": 4.0 * (F / sp) * P * P * cfg.vggt_dim,
+              "gemm_qkv": 2.0 * Ll * 3 * cfg.dim * cfg.dim, "gemm_ffn0": 2.0 * Ll * cfg.dim * cfg.ffn_dim,
+              "gemm_ffn2_gate_residual": 2.0 * Ll * cfg.dim * cfg.ffn_dim, "gemm_o_gate_residual": 2.0 * Ll * cfg.dim * cfg.dim}
+    kernels = {}
+    for name, (ms, n) in timed.items():
+        if name == "attn_hd128_self" or not n:
+            continue
+        fl = kflops.get(name)
+        kernels[name] = {"avg_launch_ms": ms, "launches_timed": n,
+                         "tflops": None if fl is None else fl / (ms * 1e-3) / 1e12,
+                         "frac_of_bf16_peak": None if fl is None else fl / (ms * 1e-3) / MFMA_BF16_PEAK}
     # HBM-side traffic of the dominant kernel: measured with rocprofv3 PMC counters in separate passes (FETCH_SIZE, WRITE_SIZE)
     # as MI355X_MICROARCH.md prescribes, recorded under profiles/ with provenance; bench.py only reports the stored measurement
-    # (a PMC pass cannot run inside the timed process).  Valid for the unsharded launch shape only.
+    # (a PMC pass cannot run inside the timed process).  Valid for the headline launch shape only.
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
-            traffic = float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"]) if topo.sp_world == 1 else None
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    headline = (not wan22 and args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
+                and args.precision == "bf16")
+    if headline and sp == 1:
+        for rnd in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
+                    traffic = float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])
+                break
+            except (OSError, KeyError, ValueError):
+                continue
+    if args.layers != 40:
+        workload = f"DEBUG {args.model} layers={args.layers} {args.frames}f x {args.height} x {args.width}"
+    elif wan22:
+        workload = (f"Wan2.2-Fun-A14B-Control-Camera + IRG fusion + VGGT branch, {args.frames}f x {args.height} x {args.width}, "
+                    f"{n_experts} expert(s) resident, random weights")
+    else:
+        workload = f"Wan2.1-I2V-14B-480P + IRG fusion + VGGT branch, {args.frames}f x {args.height} x {args.width}, random weights"
+    if headline:
+        metric = "denoise-steps/sec (81x480x832 latents, 14B WanDiT + IRG + VGGT branch)"
+    else:
+        metric = f"denoise-steps/sec ({args.frames}x{args.height}x{args.width} latents, 14B WanDiT + IRG + VGGT branch; NOT the headline config)"
     out = {
-        "metric": "denoise-steps/sec (81x480x832 latents, 14B WanDiT + IRG + VGGT branch)",
+        "metric": metric,
         "value": value, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "Wan2.1-I2V-14B-480P + IRG fusion + VGGT branch, 81f x 480 x 832, random weights"
-                               if args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
-                               else f"DEBUG layers={args.layers} {args.frames}f x {args.height} x {args.width}",
-                   "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,
-                   "parallelism": topo.describe(),
+        "dtype": "fp8_e4m3 linears (fp32 accumulate), bf16 attention" if args.precision == "fp8" else "bf16", "data": "synthetic",
+        "config": {"workload": workload, "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,
+                   "parallelism": topo.describe(), "step_invariant_cache": bool(args.cache_invariants),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
         "roofline": {"bound": "mfma", "kernel": "attention_sp_kernel<128, 1> (DiT self-attention, one launch per block"
@@ -188,11 +303,29 @@ def main():
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
                      "flops_per_launch": attn_flops, "traffic": traffic,
-                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json)",
-                     "algorithmic_bytes_per_launch": 4.0 * L * cfg.dim * 2 / topo.sp_world / n_groups},
+                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*/pmc_traffic.json)",
+                     "algorithmic_bytes_per_launch": 4.0 * L * cfg.dim * 2 / sp / n_groups},
+        "kernels": kernels,
     }
+    if args.precision == "fp8":
+        out["mfma_frac_whole_step_vs_fp8_peak"] = step_flops * value / (world * peak)
+    if comm is not None:
+        comm["note"] = ("per GPU (this is rank 0); exposed = time the compute stream was blocked inside Pending.wait(); "
+                        "issue_to_done = issue -> completion windows summed (upper bound on the exchanges' own duration)")
+        out["comm"] = comm
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, step_flops)
+        del engines, eng
+        torch.cuda.empty_cache()
+        from oracle import cpu_baseline                      # measurement infrastructure: the stated CPU baseline only
+        cb = cpu_baseline.measure(cfg, F, H2 // 2, W2 // 2, budget_s=args.cpu_budget_s)
+        raw = cb.pop("raw")
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "cpu_baseline.json"), "w") as f:
+                json.dump(dict(cb, raw=raw), f, indent=1)
+        except OSError:
+            pass
+        out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -89,16 +89,19 @@ class FusionEngine:
     """Holds the pre-packed weights of one fusion model on one device and runs joint_forward on it."""
 
     def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None, heads_cfg=None,
-                 cache_step_invariants=False):
+                 cache_step_invariants=False, precision="bf16"):
         """`get(name)` returns the reference parameter `name` (any dtype/device); tensors are packed block by block
         so a 14B model never needs a second full-precision copy.  `shard` is an optional
         fantasy_world_amd.parallel.SequenceShard (one process per GPU, RCCL).  `heads_cfg` (config.HeadsConfig) enables the
         geometry heads: joint_forward(return_prediction=True) then returns the reference's prediction dict
         (vggt.py:134-154); their weights are packed on first use.  `cache_step_invariants` keeps the intermediates that
         only depend on the prompt / camera inputs across calls (same results, bit for bit; see _InvariantCache)."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
         self.cfg = cfg
         self.ops = ops
         self.shard = shard
+        self.precision = precision
         self.heads_cfg = heads_cfg
         self._heads = None
         self._get = get

