@@ -113,7 +113,7 @@ class FusionEngine:
         ops_ = ops
         g = lambda n: get(n).detach().to(torch.float32)
 
-        def lin(wname, bname=None, k_pad=None, n_pad=None):
+        def lin(wname, bname=None, k_pad=None, n_pad=None, fp8=False):
             w = g(wname)
             w = w.reshape(w.shape[0], -1)
             b = g(bname) if bname else None
@@ -123,12 +123,12 @@ class FusionEngine:
                 w = _pad_to(w, 0, n_pad)
                 if b is not None:
                     b = _pad_to(b, 0, n_pad)
-            return ops_.pack_linear(w, b)
+            return ops_.pack_linear(w, b, fp8=True) if fp8 else ops_.pack_linear(w, b)
 
-        def lin_cat(names):
+        def lin_cat(names, fp8=False):
             w = torch.cat([g(n + ".weight") for n in names], dim=0)
             b = torch.cat([g(n + ".bias") for n in names], dim=0)
-            return ops_.pack_linear(w, b)
+            return ops_.pack_linear(w, b, fp8=True) if fp8 else ops_.pack_linear(w, b)
 
         pd = "pipe.dit."
         self.kpatch = _ru64(cfg.in_dim * 4)
@@ -171,17 +171,22 @@ class FusionEngine:
         blk = _DitBlock()
         blk.index = b
         blk.mod = ops.to_f32(g(p + "modulation").reshape(6, cfg.dim))
-        blk.qkv = lin_cat([p + "self_attn.q", p + "self_attn.k", p + "self_attn.v"])
-        blk.o = lin(p + "self_attn.o.weight", p + "self_attn.o.bias")
+        # precision "fp8": the DiT block's nn.Linear modules are the ones enable_vram_management swaps for AutoWrappedLinear
+        # (diffsynth_wan21/vram_management/layers.py:145-166, module_map {nn.Linear: AutoWrappedLinear}) -- q/k/v/o of both
+        # attentions and the FFN go through the fp8 linear; norms, modulation, the camera adapter and everything outside the
+        # DiT blocks (embeddings, head, VGGT, bicross) keep the bf16 path
+        f8 = self.precision == "fp8"
+        blk.qkv = lin_cat([p + "self_attn.q", p + "self_attn.k", p + "self_attn.v"], fp8=f8)
+        blk.o = lin(p + "self_attn.o.weight", p + "self_attn.o.bias", fp8=f8)
         blk.norm_q = ops.to_f32(g(p + "self_attn.norm_q.weight"))
         blk.norm_k = ops.to_f32(g(p + "self_attn.norm_k.weight"))
-        blk.cq = lin(p + "cross_attn.q.weight", p + "cross_attn.q.bias")
-        blk.ckv = lin_cat([p + "cross_attn.k", p + "cross_attn.v"])
-        blk.co = lin(p + "cross_attn.o.weight", p + "cross_attn.o.bias")
+        blk.cq = lin(p + "cross_attn.q.weight", p + "cross_attn.q.bias", fp8=f8)
+        blk.ckv = lin_cat([p + "cross_attn.k", p + "cross_attn.v"], fp8=f8)
+        blk.co = lin(p + "cross_attn.o.weight", p + "cross_attn.o.bias", fp8=f8)
         blk.cnorm_q = ops.to_f32(g(p + "cross_attn.norm_q.weight"))
         blk.cnorm_k = ops.to_f32(g(p + "cross_attn.norm_k.weight"))
         if cfg.has_image_input:
-            blk.ckv_img = lin_cat([p + "cross_attn.k_img", p + "cross_attn.v_img"])
+            blk.ckv_img = lin_cat([p + "cross_attn.k_img", p + "cross_attn.v_img"], fp8=f8)
             blk.cnorm_k_img = ops.to_f32(g(p + "cross_attn.norm_k_img.weight"))
         blk.adapter = cfg.has_adapter(b)
         if blk.adapter:
@@ -194,8 +199,8 @@ class FusionEngine:
             blk.a_v2 = lin(a + "v_proj.group2.2.weight", a + "v_proj.group2.2.bias", k_pad=rp)   # 409 -> 448 cols (zeros)
         blk.norm3_w = ops.to_f32(g(p + "norm3.weight"))
         blk.norm3_b = ops.to_f32(g(p + "norm3.bias"))
-        blk.ffn0 = lin(p + "ffn.0.weight", p + "ffn.0.bias")
-        blk.ffn2 = lin(p + "ffn.2.weight", p + "ffn.2.bias")
+        blk.ffn0 = lin(p + "ffn.0.weight", p + "ffn.0.bias", fp8=f8)
+        blk.ffn2 = lin(p + "ffn.2.weight", p + "ffn.2.bias", fp8=f8)
         return blk
 
     def _pack_vggt(self, p, g, lin):

@@ -67,7 +67,7 @@ def load_library(path: str = LIB_PATH):
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
         "fw_softmax_rows": [vp, i64, vp, i64, i32, i32, i32, f32, vp],
         "fw_fp8_quant_rows": [vp, i64, vp, i64, vp, i32, i32, i32, vp],
-        "fw_gemm_fp8": [vp, i64, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp],
+        "fw_gemm_fp8": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
         "fw_pixel_unshuffle": [vp, i32, vp, i64, i32, i32, i32, i32, i32, vp],
         "fw_group_norm_rows": [vp, i64, vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp],
         "fw_time_avg_pool": [vp, i64, vp, i64, i32, i32, i32, vp],
@@ -85,7 +85,7 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
-    if lib.fw_abi_version() != 6:
+    if lib.fw_abi_version() != 7:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -110,11 +110,13 @@ def _dt(t):
 
 
 class Linear:
-    """Pre-packed nn.Linear: bf16 weight [N, K] (K % 64 == 0, zero padded), fp32 bias [N]."""
-    __slots__ = ("w", "b", "N", "K")
+    """Pre-packed nn.Linear: bf16 weight [N, K] (K % 64 == 0, zero padded), fp32 bias [N].
+    fp8 = True: the weight is e4m3 bytes (raw cast) and the bias holds bf16-rounded values -- AutoWrappedLinear.fp8_linear's
+    operands (diffsynth_wan22/vram_management/layers.py:134-138); HipOps.linear then quantises the activation rows."""
+    __slots__ = ("w", "b", "N", "K", "fp8")
 
-    def __init__(self, w, b):
-        self.w, self.b = w, b
+    def __init__(self, w, b, fp8=False):
+        self.w, self.b, self.fp8 = w, b, fp8
         self.N, self.K = w.shape
 
 
@@ -194,8 +196,10 @@ class HipOps:
     def to_act(self, t):
         return t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
 
-    def pack_linear(self, w, b):
-        """w fp32/bf16 [N, K] with K % 64 == 0 (engine pads), b [N] or None."""
+    def pack_linear(self, w, b, fp8=False):
+        """w fp32/bf16 [N, K] with K % 64 == 0 (engine pads), b [N] or None.  fp8: pack for the fp8 linear instead."""
+        if fp8:
+            return self.pack_linear_fp8(w, b)
         assert w.shape[1] % 64 == 0, w.shape
         wb = w.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
         bb = None if b is None else b.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -209,6 +213,8 @@ class HipOps:
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1, (x.dtype, x.shape, x.stride())
         M, K = x.shape
         assert K == lin.K, (K, lin.K)
+        if lin.fp8:
+            return self._linear_fp8(x, lin, act, g1, g0, res, out_f32, out)
         if out is None:
             out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
         assert out.shape == (M, lin.N) and out.stride(1) == 1
@@ -491,7 +497,7 @@ class HipOps:
         _check(self.lib.fw_fp8_quant_rows(wb.data_ptr(), wb.stride(0), wq.data_ptr(), wq.stride(0), None, wb.shape[0], wb.shape[1],
                                           1, self._stream()), "fw_fp8_quant_rows")
         bb = None if b is None else b.detach().to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous()
-        return Linear(wq, bb)
+        return Linear(wq, bb, fp8=True)
 
     def quantize_fp8_rows(self, x):
         """x bf16 [M, K] -> (e4m3 bytes [M, K], fp32 scale [M]): the per-row activation quantiser of fp8_linear."""
@@ -502,15 +508,30 @@ class HipOps:
                                           x.shape[1], 0, self._stream()), "fw_fp8_quant_rows")
         return q, scale
 
-    def linear_fp8(self, x, lin, out_f32=False):
-        """fp8_linear(x, w, b): quantise the rows of x, e4m3 x e4m3 GEMM with fp32 accumulation, * scale_a + bias -> x.dtype."""
-        q, scale = self.quantize_fp8_rows(x)
+    def _linear_fp8(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
+        """fp8_linear(x, w, b) with the bf16 linear's fused epilogue: quantise the rows of x, e4m3 x e4m3 GEMM with fp32
+        accumulation, * scale_a + bias -> act -> per-column affine -> + residual."""
         M, K = x.shape
-        assert K == lin.K
-        out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
-        _check(self.lib.fw_gemm_fp8(q.data_ptr(), q.stride(0), lin.w.data_ptr(), lin.w.stride(0), scale.data_ptr(), _ptr(lin.b),
-                                    out.data_ptr(), out.stride(0), _dt(out), M, lin.N, K, self._stream()), "fw_gemm_fp8")
+        q, scale = self.quantize_fp8_rows(x)
+        if out is None:
+            out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
+        assert out.shape == (M, lin.N) and out.stride(1) == 1
+        if res is not None:
+            assert res.shape == (M, lin.N) and res.stride(1) == 1
+        tok = None if self._timing is None else self._time_begin(
+            dict(kind="linear", M=M, N=lin.N, K=K, res=res is not None, out_f32=out.dtype == torch.float32, act=act, fp8=True))
+        _check(self.lib.fw_gemm_fp8(
+            q.data_ptr(), q.stride(0), lin.w.data_ptr(), lin.w.stride(0), scale.data_ptr(), out.data_ptr(), out.stride(0),
+            _dt(out), M, lin.N, K, _ptr(lin.b), ACT[act], _ptr(g1), _ptr(g0),
+            _ptr(res), 0 if res is None else res.stride(0), FW_DT_NONE if res is None else _dt(res),
+            self._stream()), "fw_gemm_fp8")
+        self._time_end(tok)
         return out
+
+    def linear_fp8(self, x, lin, out_f32=False):
+        """fp8_linear(x, w, b): (xq wq^T) * scale_a + bias -> x.dtype (or fp32)."""
+        assert lin.fp8
+        return self._linear_fp8(x, lin, out_f32=out_f32)
 
     def cast_act(self, x):
         assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 6
+#define FW_ABI_VERSION 7
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -296,11 +296,18 @@ int fw_softmax_rows(const float* s, int64_t lds, uint16_t* out, int64_t ldo, int
  * x bf16 [M][K] (ldx), q bytes [M][K] (ldq), round-to-nearest-even. */
 int fw_fp8_quant_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int M, int K, int raw, void* stream);
 
-/* C[M][N] = (A[M][K] W[N][K]^T) * scale_a[m] + bias[n]  -- torch._scaled_mm(xq, wq^T, scale_a, 1, bias, out_dtype)
- * (layers.py:141-148) on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation; A, W e4m3 bytes (K % 64 == 0), bias fp32 holding
- * bf16-rounded values (or NULL), out_dtype FW_DT_BF16 / FW_DT_F32. */
-int fw_gemm_fp8(const uint8_t* A, int64_t lda, const uint8_t* W, int64_t ldw, const float* scale_a, const float* bias,
-                void* C, int64_t ldc, int out_dtype, int M, int N, int K, void* stream);
+/* C[M][N] = epi((A[M][K] W[N][K]^T) * scale_a[m] + bias[n])  -- torch._scaled_mm(xq, wq^T, scale_a, 1, bias, out_dtype)
+ * (layers.py:141-148), fp32 accumulation; A, W e4m3 bytes (K % 64 == 0), bias fp32 holding bf16-rounded values (or NULL).
+ * The epilogue after the scaled product is fw_gemm_bf16's (act -> per-column affine g1/g0 -> + residual -> out_dtype), so the
+ * fp8 linear drops into every place the engine calls a bf16 linear: this is the module swap enable_vram_management performs
+ * (diffsynth_wan21/vram_management/layers.py:145-166, module_map = {nn.Linear: AutoWrappedLinear}) with the surrounding
+ * gate / residual arithmetic of the block fused in.  M >= 2048, N >= 1024, K % 128 == 0: 256x256x128 ping-pong kernel on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (the fp8-rate instruction of gfx950); otherwise a 128x128 kernel on
+ * v_mfma_f32_32x32x16_fp8_fp8. */
+int fw_gemm_fp8(const uint8_t* A, int64_t lda, const uint8_t* W, int64_t ldw, const float* scale_a,
+                void* C, int64_t ldc, int out_dtype, int M, int N, int K,
+                const float* bias, int act, const float* g1, const float* g0,
+                const void* res, int64_t ldr, int res_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,33 @@ def sdpa(q, k, v, num_heads):
     return o.transpose(1, 2).reshape(b, lq, -1)
 
 
+# fp8 mode (BASELINE config 5): the nn.Linear modules of the DiT blocks computed by AutoWrappedLinear.fp8_linear, as
+# enable_vram_management(dit, module_map={nn.Linear: AutoWrappedLinear}, computation_dtype=float8_e4m3fn) would make them
+# (diffsynth_wan21/vram_management/layers.py:145-166; diffsynth_wan22/vram_management/layers.py:113-151).  Set through
+# joint_forward(fp8_linears=True); the camera-adapter processor's small linears keep full precision (the engine's choice, stated in
+# DESIGN.md -- the reference defines no fp8 run of the fusion model at all).
+_FP8 = {"on": False}
+_FP8_SITES = (".self_attn.q", ".self_attn.k", ".self_attn.v", ".self_attn.o", ".cross_attn.q", ".cross_attn.k", ".cross_attn.v",
+              ".cross_attn.o", ".cross_attn.k_img", ".cross_attn.v_img", ".ffn.0", ".ffn.2")
+
+
+def fp8_linear(x, weight, bias):
+    """AutoWrappedLinear.fp8_linear (diffsynth_wan22/vram_management/layers.py:115-151) for e4m3fn, with torch._scaled_mm written
+    as its definition (a @ b) * scale_a * scale_b + bias -> out_dtype (the call itself only exists on GPU back-ends).  The
+    reference runs it on bf16 activations / weights and gets bf16 back: the fp32 pipeline of this oracle rounds at those two points."""
+    shape = x.shape
+    xb = x.reshape(-1, shape[-1]).to(torch.bfloat16)                                    # origin_dtype = bf16
+    x_max = torch.max(torch.abs(xb), dim=-1, keepdim=True).values
+    scale_a = torch.clamp(x_max / 448.0, min=1.0).float()
+    xq = (xb / (scale_a + 1e-8)).to(torch.float8_e4m3fn)
+    wq = weight.to(torch.bfloat16).to(torch.float8_e4m3fn)
+    y = (xq.float() @ wq.float().t()) * scale_a + bias.to(torch.bfloat16).float()
+    return y.to(torch.bfloat16).float().reshape(*shape[:-1], -1)
+
+
 def linear(x, W, name):
+    if _FP8["on"] and name.endswith(_FP8_SITES) and ("pipe.dit.blocks." in name or ".x_dit." in name):
+        return fp8_linear(x, W[name + ".weight"], W[name + ".bias"])
     return F.linear(x, W[name + ".weight"], W[name + ".bias"])
 
 
@@ -247,7 +273,17 @@ def control_adapter(ctl, W, pre):
 
 
 def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
-                  plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None):
+                  plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None, fp8_linears=False):
+    _FP8["on"] = bool(fp8_linears)
+    try:
+        return _joint_forward(W, cfg, x, timestep, context, clip_feature, y, plucker_fea, plucker_context_lens, uncond, collect,
+                              control_camera_latents_input)
+    finally:
+        _FP8["on"] = False
+
+
+def _joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
+                   plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None):
     """W: name -> fp32 tensor (reference parameter names). Returns noise_pred [1,16,F,H,W] (fp32).
     Pass collect={"output_list": {}} to receive the aggregator's output_list (layer -> [f, P, 2C]), the input of the geometry
     heads (oracle/fw_heads_oracle.py restates VGGT._head_predction on it)."""

@@ -16,10 +16,10 @@ import torch.nn.functional as F
 
 
 class _Lin:
-    __slots__ = ("w", "b", "N", "K")
+    __slots__ = ("w", "b", "N", "K", "fp8")
 
-    def __init__(self, w, b):
-        self.w, self.b = w, b
+    def __init__(self, w, b, fp8=False):
+        self.w, self.b, self.fp8 = w, b, fp8
         self.N, self.K = w.shape
 
 
@@ -44,8 +44,10 @@ class TorchRefOps:
     def to_act(self, t):
         return self._r(t.detach().to(device=self.device, dtype=torch.float32)).contiguous()
 
-    def pack_linear(self, w, b):
+    def pack_linear(self, w, b, fp8=False):
         assert w.shape[1] % 64 == 0
+        if fp8:
+            return self.pack_linear_fp8(w, b)
         return _Lin(self._r(self.to_f32(w)), None if b is None else self.to_f32(b))
 
     def pack_linear_f32(self, w, b):
@@ -68,7 +70,11 @@ class TorchRefOps:
 
     def linear(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
         assert x.shape[1] == lin.K
-        y = x.to(torch.float32) @ lin.w.t()
+        if lin.fp8:      # fp8_linear (layers.py:115-151) by its definition, then the same epilogue
+            q, scale = self.quantize_fp8_rows(x)
+            y = (q.float() @ lin.w.float().t()) * scale[:, None]
+        else:
+            y = x.to(torch.float32) @ lin.w.t()
         if lin.b is not None:
             y = y + lin.b
         y = self._act(y, act)
@@ -310,7 +316,7 @@ class TorchRefOps:
     # ---- fp8 linear ----------------------------------------------------------------------------------------
     def pack_linear_fp8(self, w, b):
         wq = self.to_f32(w).to(torch.bfloat16).to(torch.float8_e4m3fn)               # raw cast (layers.py:137)
-        return _Lin(wq, None if b is None else self.to_f32(b).to(torch.bfloat16).to(torch.float32))
+        return _Lin(wq, None if b is None else self.to_f32(b).to(torch.bfloat16).to(torch.float32), fp8=True)
 
     def quantize_fp8_rows(self, x):
         """AutoWrappedLinear.fp8_linear lines 126-136 on bf16-representable x [M, K]: (e4m3 tensor, fp32 scale [M])."""
@@ -321,8 +327,4 @@ class TorchRefOps:
 
     def linear_fp8(self, x, lin, out_f32=False):
         """torch._scaled_mm(xq, wq^T, scale_a, 1, bias, out_dtype) by its definition: (xq @ wq^T) * scale_a + bias."""
-        q, scale = self.quantize_fp8_rows(x)
-        y = (q.float() @ lin.w.float().t()) * scale[:, None]
-        if lin.b is not None:
-            y = y + lin.b
-        return y if out_f32 else self._r(y)
+        return self.linear(x, lin, out_f32=out_f32)
