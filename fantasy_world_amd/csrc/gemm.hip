@@ -157,57 +157,86 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // bias / activation / per-column affine are applied on the way in (column == lane in the accumulator layout).
 __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x16_t (&acc)[4][2], int wave, int grp, int wn,
                                              int fi, int hi, int lane, int m0, int n0) {
-    {
-        char* reg = smem + wave * 16384;
-        float bias2[2], g12[2], g02[2];
+    char* reg = smem + wave * 16384;
+    float bias2[2], g12[2], g02[2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int col = n0 + wn * 64 + nb * 32 + fi;
-            const bool ok = col < p.N;
-            bias2[nb] = (p.bias && ok) ? p.bias[col] : 0.f;
-            g12[nb] = (p.g1 && ok) ? p.g1[col] : 1.f;
-            g02[nb] = (p.g0 && ok) ? p.g0[col] : 0.f;
-        }
-        const int rl = lane >> 4;              // row inside a 4-row read group
-        const int c4 = (lane & 15) * 4;        // first of this lane's 4 columns
-        const int gcol = n0 + wn * 64 + c4;
+    for (int nb = 0; nb < 2; ++nb) {
+        const int col = n0 + wn * 64 + nb * 32 + fi;
+        const bool ok = col < p.N;
+        bias2[nb] = (p.bias && ok) ? p.bias[col] : 0.f;
+        g12[nb] = (p.g1 && ok) ? p.g1[col] : 1.f;
+        g02[nb] = (p.g0 && ok) ? p.g0[col] : 0.f;
+    }
+    const int rl = lane >> 4;              // row inside a 4-row read group
+    const int c4 = (lane & 15) * 4;        // first of this lane's 4 columns
+    const int gcol = n0 + wn * 64 + c4;
+    const bool col_ok = gcol < p.N;
+    // One 64-row pass: (1) ALL 16 residual loads of the pass are issued first -- 16 KiB per wave, 128 KiB per CU in flight, so the
+    // HBM latency of the fp32 stream is paid once per pass and runs under the LDS transpose instead of once per 4 rows --
+    // (2) accumulators -> LDS with bias / activation / affine, (3) row-contiguous read-back, + residual, 16-B stores.
+    auto pass = [&](auto q_tag, auto res_tag) {
+        constexpr int q = decltype(q_tag)::value;              // compile-time: acc[] must never be indexed dynamically
+        constexpr int RES = decltype(res_tag)::value;          // FW_DT_NONE / FW_DT_BF16 / FW_DT_F32
+        f32x4_t rv[16];
+        u32x2_t rw[16];
+        if (RES != FW_DT_NONE) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int rb2 = 0; rb2 < 2; ++rb2)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[2 * q + rb2][nb][r] + bias2[nb];
-                        v = fw_apply_act(v, p.act);
-                        v = v * g12[nb] + g02[nb];
-                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
-                    }
-#pragma unroll 4
             for (int it = 0; it < 16; ++it) {
-                const int row_l = it * 4 + rl;
-                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
-                const int row = m0 + grp * 128 + q * 64 + row_l;
-                if (row < p.M && gcol < p.N) {
-                    if (p.res_dtype == FW_DT_F32) {
-                        const f32x4_t rv = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
-                        v += rv;
-                    } else if (p.res_dtype == FW_DT_BF16) {
-                        const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
-                        v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
-                        v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
-                    }
-                    if (p.out_dtype == FW_DT_F32) {
-                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
-                    } else {
-                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
-                    }
+                const int row = m0 + grp * 128 + q * 64 + it * 4 + rl;
+                const bool ok = row < p.M && col_ok;
+                if (RES == FW_DT_F32) {
+                    rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+                } else {
+                    rw[it] = u32x2_t{0u, 0u};
+                    if (ok) rw[it] = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
                 }
             }
         }
+#pragma unroll
+        for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[2 * q + rb2][nb][r] + bias2[nb];
+                    v = fw_apply_act(v, p.act);
+                    v = v * g12[nb] + g02[nb];
+                    const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
+                }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row_l = it * 4 + rl;
+            f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
+            const int row = m0 + grp * 128 + q * 64 + row_l;
+            if (RES == FW_DT_F32) {
+                v += rv[it];
+            } else if (RES == FW_DT_BF16) {
+                v[0] += __uint_as_float(rw[it][0] << 16); v[1] += __uint_as_float(rw[it][0] & 0xffff0000u);
+                v[2] += __uint_as_float(rw[it][1] << 16); v[3] += __uint_as_float(rw[it][1] & 0xffff0000u);
+            }
+            if (row < p.M && col_ok) {
+                if (p.out_dtype == FW_DT_F32) {
+                    *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                } else {
+                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                }
+            }
+        }
+    };
+    using Q0 = std::integral_constant<int, 0>;
+    using Q1 = std::integral_constant<int, 1>;
+    if (p.res_dtype == FW_DT_F32) {
+        pass(Q0{}, std::integral_constant<int, FW_DT_F32>{});
+        pass(Q1{}, std::integral_constant<int, FW_DT_F32>{});
+    } else if (p.res_dtype == FW_DT_BF16) {
+        pass(Q0{}, std::integral_constant<int, FW_DT_BF16>{});
+        pass(Q1{}, std::integral_constant<int, FW_DT_BF16>{});
+    } else {
+        pass(Q0{}, std::integral_constant<int, FW_DT_NONE>{});
+        pass(Q1{}, std::integral_constant<int, FW_DT_NONE>{});
     }
 }
 
@@ -893,6 +922,168 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second generation of the ping-pong kernel (round 2, the default).  Same tile, LDS image, slot table, DMA placement, counted waits
+// and fragment reads as gemm_bf16_pp_kernel; what changed was read off the ISA:
+//   * the loop is peeled by hand (first / steady / second-last / last slab as compile-time flags), so a phase is ONE basic block;
+//   * the accumulators are pinned by an empty asm after every burst, so no MFMA drifts across the barrier that follows.
+// +2..5 % on the DiT shapes (profiles/r02/gemm_experiments.md).  Tried on this skeleton and measured WITHOUT gain, hence not kept:
+// LDS-DMA issued from the LOAD phases instead of from inside the bursts (+-0), the slot barrier signalled one k-step early so its
+// release latency runs under the last MFMAs (+-0), a software L2 prefetch 3-4 slabs ahead (-10 %: the extra line requests cost
+// more than the misses they hide), a rotated K start per work-group against channel hot-spotting (-6 %: it breaks the lockstep L2
+// sharing of A bands / W panels), staggered work-group starts to de-phase the residual epilogues (-3..-20 %).  The TIMING build
+// (TS, tools/gemm_timeline.py) stamps s_memtime at the phase boundaries.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ unsigned long long g_gemm_ts[2 * 64];     // TIMING build: [group][slab 0..3][phase 0..3][start | end of work]
+
+template <bool TS>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[2][2], woff[2][2];       // [unit][piece]
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = u * 128 + (wave * 2 + i) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            aoff[u][i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+            woff[u][i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+        }
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int coff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + hi) ^ swz) << 4;
+    const int a_row_off = (grp * 128 + fi) * 128;
+    const int b_row_off = TM * BK * 2 + (wn * 64 + fi) * 128;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t afr[2][4], bfr[2][4];
+
+    const int nk = p.K / BK;       // >= 4 (launcher)
+    FW_PP_ISSUE6(0, 0); FW_PP_ISSUE2(0, 0);
+    FW_PP_ISSUE6(1, 1); FW_PP_ISSUE2(1, 1);
+    fw_wait_vm<8>();
+    FW_BARRIER();
+    if (grp == 1) FW_BARRIER();
+
+    int kt = 0;
+    auto slab = [&](auto first_tag, auto has1_tag, auto has2_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value, HAS1 = decltype(has1_tag)::value, HAS2 = decltype(has2_tag)::value;
+        const int st = kt & 1;
+        const char* base = smem + st * STAGE2;
+        // TIMING build: s_memtime at the start (barrier passed) and at the end of the work of every phase, slabs 16..19, work-group 0
+        const bool ts_on = TS && blockIdx.x == 0 && wn == 0 && kt >= 16 && kt < 20;
+        auto stamp = [&](int phase, int which) {
+            if (ts_on) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) g_gemm_ts[grp * 64 + (kt - 16) * 8 + phase * 2 + which] = t;
+            }
+        };
+        stamp(0, 0);
+        // ---------------- LOAD0(kt): B fragments + A rows 0..63 of the wave tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bfr[0][ks] = *(const bf16x8_t*)(base + b_row_off + coff[ks]);
+            bfr[1][ks] = *(const bf16x8_t*)(base + b_row_off + 32 * 128 + coff[ks]);
+            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + coff[ks]);
+            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 32 * 128 + coff[ks]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 0) { if (HAS1) fw_wait_vm<6>(); else fw_wait_vm<0>(); }
+        stamp(0, 1);
+        FW_BARRIER();
+        stamp(1, 0);
+        // ---------------- MFMA0(kt) (+ A1 unit of slab kt+1 into the other stage; slabs 0 and 1 come from the prologue)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[0][1], 0, 0, 0);
+            if (ks == 0 && !FIRST && HAS1) FW_PP_ISSUE2(st ^ 1, kt + 1);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        stamp(1, 1);
+        FW_BARRIER();
+        stamp(2, 0);
+        // ---------------- LOAD1(kt): A rows 64..127 of the wave tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + 64 * 128 + coff[ks]);
+            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 96 * 128 + coff[ks]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) { if (HAS1) fw_wait_vm<2>(); else fw_wait_vm<0>(); }
+        stamp(2, 1);
+        FW_BARRIER();
+        stamp(3, 0);
+        // ---------------- MFMA1(kt) (+ B and A0 units of slab kt+2 into this stage)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[2][1], 0, 0, 0);
+            if (ks == 0 && HAS2) FW_PP_ISSUE6(st, kt + 2);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[3][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("" : "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+        stamp(3, 1);
+        if (grp == 0) { if (HAS2) fw_wait_vm<8>(); else if (HAS1) fw_wait_vm<2>(); else fw_wait_vm<0>(); }
+        else { if (HAS2) fw_wait_vm<6>(); else fw_wait_vm<0>(); }
+        FW_BARRIER();
+        ++kt;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    slab(T{}, T{}, T{});
+    while (kt < nk - 2) slab(F{}, T{}, T{});
+    slab(F{}, T{}, F{});
+    slab(F{}, F{}, F{});
+    if (grp == 0) FW_BARRIER();
+    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
+}
+
 // fp32 GEMV for the M=1 time-embedding MLPs: one wave per output feature.
 __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, float* __restrict__ out,
@@ -950,7 +1141,7 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         // kernel (512 tiles = 2 rounds), the <= 128 leftover rows to the 128x128 kernel in a second, tiny launch.  Same
         // k-order per output element in both kernels, disjoint output rows.
         const int tail = M % TM;
-        if (kern == 3 && tail > 0 && tail <= BM && M >= 2 * TM) {
+        if ((kern == 3 || kern == 4) && tail > 0 && tail <= BM && M >= 2 * TM) {
             const int Mfull = M - tail;
             const size_t cbytes = (out_dtype == FW_DT_F32) ? 4 : 2, rbytes = (res_dtype == FW_DT_F32) ? 4 : 2;
             int rc = fw_gemm_bf16(A, lda, W, ldw, C, ldc, out_dtype, Mfull, N, K, bias, act, g1, g0, res, ldr, res_dtype, stream);
@@ -969,6 +1160,11 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
         const int var = fw_get_option(FW_OPT_GEMM_VAR);
         hipStream_t st = (hipStream_t)stream;
+        if (kern == 4 && K >= 4 * BK) {
+            if (var & 2) hipLaunchKernelGGL(gemm_bf16_pp2_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+            else hipLaunchKernelGGL(gemm_bf16_pp2_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+            return (int)hipGetLastError();
+        }
         if (kern == 3 && K >= 4 * BK) {
             if (var == 1) hipLaunchKernelGGL(gemm_bf16_pp_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p);
             else hipLaunchKernelGGL(gemm_bf16_pp_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p);
@@ -1017,6 +1213,12 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
+}
+
+// Measurement hook (tools/gemm_timeline.py): the phase timestamps written by the TIMING build of the ping-pong kernel.
+extern "C" int fw_debug_gemm_timestamps(unsigned long long* host_out, int n) {
+    if (n <= 0 || n > 128) { fw_set_error("fw_debug_gemm_timestamps: n must be in 1..128"); return FW_E_BADARG; }
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_ts), sizeof(unsigned long long) * n);
 }
 
 extern "C" int fw_gemv_f32(const float* x, const float* W, int64_t ldw, const float* bias, float* out,

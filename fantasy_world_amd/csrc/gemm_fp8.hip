@@ -187,10 +187,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
     FWQ_BARRIER();
     if (grp == 1) FWQ_BARRIER();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* base = smem + (kt & 1) * QSTAGE;
+    // One slab.  The three conditions are compile-time (the loop is peeled by hand: first / steady / second-last / last slab), so
+    // a phase is ONE basic block: with run-time branches inside, LLVM sinks every MFMA of the slab past the barriers into the last
+    // block and the ping-pong degenerates (seen in the ISA).  After each burst the accumulators are pinned by an empty asm, which
+    // keeps the MFMAs on their side of the barrier that follows.
+    int kt = 0;
+    auto slab = [&](auto first_tag, auto has1_tag, auto has2_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value, HAS1 = decltype(has1_tag)::value, HAS2 = decltype(has2_tag)::value;
         const int st = kt & 1;
-        const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+        const char* base = smem + st * QSTAGE;
         // ---------------- LOAD0(kt): B fragments + A rows 0..63 of the wave tile
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
             afr[1][s] = fwq_frag(base + a_row_off + 32 * 128, c0[s], c1[s]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 0) { if (has1) fwq_wait_vm<6>(); else fwq_wait_vm<0>(); }
+        if (grp == 0) { if (HAS1) fwq_wait_vm<6>(); else fwq_wait_vm<0>(); }
         FWQ_BARRIER();
         // ---------------- MFMA0(kt) (+ A1 unit of slab kt+1 into the other stage; slabs 0 and 1 come from the prologue)
         __builtin_amdgcn_s_setprio(1);
@@ -208,11 +213,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
         for (int s = 0; s < 2; ++s) {
             acc[0][0] = FWQ_MFMA(afr[0][s], bfr[0][s], acc[0][0]);
             acc[0][1] = FWQ_MFMA(afr[0][s], bfr[1][s], acc[0][1]);
-            if (s == 0 && kt >= 1 && has1) FWQ_ISSUE2(st ^ 1, kt + 1);
+            if (s == 0 && !FIRST && HAS1) FWQ_ISSUE2(st ^ 1, kt + 1);
             acc[1][0] = FWQ_MFMA(afr[1][s], bfr[0][s], acc[1][0]);
             acc[1][1] = FWQ_MFMA(afr[1][s], bfr[1][s], acc[1][1]);
         }
         __builtin_amdgcn_s_setprio(0);
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
         FWQ_BARRIER();
         // ---------------- LOAD1(kt): A rows 64..127 of the wave tile
 #pragma unroll
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
             afr[1][s] = fwq_frag(base + a_row_off + 96 * 128, c0[s], c1[s]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 1) { if (has1) fwq_wait_vm<2>(); else fwq_wait_vm<0>(); }
+        if (grp == 1) { if (HAS1) fwq_wait_vm<2>(); else fwq_wait_vm<0>(); }
         FWQ_BARRIER();
         // ---------------- MFMA1(kt) (+ B and A0 units of slab kt+2 into this stage)
         __builtin_amdgcn_s_setprio(1);
@@ -229,15 +235,23 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
         for (int s = 0; s < 2; ++s) {
             acc[2][0] = FWQ_MFMA(afr[0][s], bfr[0][s], acc[2][0]);
             acc[2][1] = FWQ_MFMA(afr[0][s], bfr[1][s], acc[2][1]);
-            if (s == 0 && has2) FWQ_ISSUE6(st, kt + 2);
+            if (s == 0 && HAS2) FWQ_ISSUE6(st, kt + 2);
             acc[3][0] = FWQ_MFMA(afr[1][s], bfr[0][s], acc[3][0]);
             acc[3][1] = FWQ_MFMA(afr[1][s], bfr[1][s], acc[3][1]);
         }
         __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) { if (has2) fwq_wait_vm<8>(); else if (has1) fwq_wait_vm<2>(); else fwq_wait_vm<0>(); }
-        else { if (has2) fwq_wait_vm<6>(); else fwq_wait_vm<0>(); }
+        asm volatile("" : "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+        if (grp == 0) { if (HAS2) fwq_wait_vm<8>(); else if (HAS1) fwq_wait_vm<2>(); else fwq_wait_vm<0>(); }
+        else { if (HAS2) fwq_wait_vm<6>(); else fwq_wait_vm<0>(); }
         FWQ_BARRIER();
-    }
+        ++kt;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    slab(T{}, T{}, T{});                                   // kt = 0 (nk >= 4)
+    while (kt < nk - 2) slab(F{}, T{}, T{});
+    slab(F{}, T{}, F{});                                   // kt = nk - 2
+    slab(F{}, F{}, F{});                                   // kt = nk - 1
     if (grp == 0) FWQ_BARRIER();
     epilogue_fp8(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
 }

@@ -22,7 +22,7 @@ ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
 SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
-    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_control_patchify", "fw_im2col3x3",
+    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_debug_gemm_timestamps", "fw_control_patchify", "fw_im2col3x3",
     "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
@@ -62,6 +62,7 @@ def load_library(path: str = LIB_PATH):
         "fw_cast_f32_bf16": [vp, i64, vp, i64, i32, i32, vp],
         "fw_set_option": [i32, i32],
         "fw_debug_attention_timestamps": [vp, i32],
+        "fw_debug_gemm_timestamps": [vp, i32],
         "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -210,11 +211,11 @@ class HipOps:
 
     # ---- GEMM -------------------------------------------------------------------------------------------------
     def linear(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
+        if lin.fp8:
+            return self._linear_fp8(x, lin, act, g1, g0, res, out_f32, out)
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1, (x.dtype, x.shape, x.stride())
         M, K = x.shape
         assert K == lin.K, (K, lin.K)
-        if lin.fp8:
-            return self._linear_fp8(x, lin, act, g1, g0, res, out_f32, out)
         if out is None:
             out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
         assert out.shape == (M, lin.N) and out.stride(1) == 1
@@ -511,8 +512,10 @@ class HipOps:
     def _linear_fp8(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
         """fp8_linear(x, w, b) with the bf16 linear's fused epilogue: quantise the rows of x, e4m3 x e4m3 GEMM with fp32
         accumulation, * scale_a + bias -> act -> per-column affine -> + residual."""
-        M, K = x.shape
-        q, scale = self.quantize_fp8_rows(x)
+        # x: bf16 rows, or rows already quantised by quantize_fp8_rows: (e4m3 bytes [M, K], fp32 scale [M])
+        q, scale = x if isinstance(x, tuple) else self.quantize_fp8_rows(x)
+        M, K = q.shape
+        assert K == lin.K and q.dtype == torch.uint8 and q.stride(1) == 1 and scale.numel() == M, (q.shape, lin.K)
         if out is None:
             out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
         assert out.shape == (M, lin.N) and out.stride(1) == 1

@@ -75,6 +75,7 @@ int fw_set_option(int opt, int value);
 
 /* Measurement hook: shader-clock timestamps [wave 0..7][8] of work-group 0 at KV tile 100, written by the TIMING build of the
  * ping-pong attention kernel (FW_ATTN_VAR = 66); synchronous copy to host memory. */
+int fw_debug_gemm_timestamps(unsigned long long* host_out, int n);   /* same, GEMM ping-pong kernel (FW_GEMM_KERNEL=4, var bit 1) */
 int fw_debug_attention_timestamps(unsigned long long* host_out, int n);
 
 /* Human-readable description of the last negative error on this thread (never NULL). */

@@ -63,6 +63,37 @@ def test_fp8_linear_matches_torch_statement(ops, ref, M, N, K):
     assert got16.dtype == torch.bfloat16 and rel_l2(got16.float(), want) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 512), (2304, 1280, 1024), (4096 + 97, 1152, 5120), (2048 + 200, 2048, 640)])
+def test_fp8_pingpong_kernel_matches_torch_statement(ops, ref, M, N, K, parity):
+    """Shapes that take the 256x256x128 ping-pong kernel on v_mfma_scale_f32_32x32x64_f8f6f4 (M >= 2048, N >= 1024, K % 128 == 0):
+    full tiles, ragged N, the peeled <= 128-row M tail (4096 + 97), a ragged last band (2048 + 200), 4..40 k-slabs.  The products
+    of e4m3 values are exact in fp32; only the summation order differs from the CPU's."""
+    x, w, b = rnd(M, K, seed=3, scale=4.0), rnd(N, K, seed=4, scale=K ** -0.5), rnd(N, seed=5, scale=0.1)
+    x[0, 0] = 3000.0
+    x[M - 1, 5] = -2000.0
+    want = ref.linear_fp8(x, ref.pack_linear_fp8(w, b), out_f32=True)
+    lin = ops.pack_linear_fp8(w, b)
+    xd = x.to(torch.bfloat16).cuda()
+    got32 = ops.linear_fp8(xd, lin, out_f32=True)
+    got16 = ops.linear_fp8(xd, lin)
+    parity.check(f"op/fp8_pp_f32out/{M}x{N}x{K}", rel_l2(got32, want), 1e-4)
+    parity.check(f"op/fp8_pp_bf16out/{M}x{N}x{K}", rel_l2(got16.float(), want), 4e-3)
+    assert (got32.cpu() - want).abs().max() < 1e-3 * want.abs().max()
+
+
+def test_fp8_linear_fused_epilogue(ops, ref, parity):
+    """The fp8 linear with the bf16 linear's epilogue (act -> per-column affine -> + fp32 residual in place), both kernels."""
+    for (M, N, K) in [(2560, 1024, 1024), (300, 320, 256)]:
+        x, w, b = rnd(M, K, seed=8, scale=2.0), rnd(N, K, seed=9, scale=K ** -0.5), rnd(N, seed=10, scale=0.1)
+        g1, g0, res = rnd(N, seed=11), rnd(N, seed=12, scale=0.1), rnd(M, N, seed=13)
+        want = ref.linear(x, ref.pack_linear_fp8(w, b), act="gelu_tanh", g1=g1, g0=g0, res=res, out_f32=True)
+        stream = res.cuda().clone()
+        got = ops.linear(x.to(torch.bfloat16).cuda(), ops.pack_linear_fp8(w, b), act="gelu_tanh", g1=g1.cuda(), g0=g0.cuda(),
+                         res=stream, out_f32=True, out=stream)
+        assert got.data_ptr() == stream.data_ptr()
+        parity.check(f"op/fp8_fused_epilogue/{M}x{N}x{K}", rel_l2(got, want), 1e-4)
+
+
 def test_fp8_linear_against_bf16_linear(ops):
     """What the option costs in accuracy: e4m3 activations and raw-cast weights against the bf16 GEMM on the same operands --
     a few percent, the reference's own trade-off (no reference semantics exist beyond fp8_linear itself; stated, not tuned)."""

@@ -48,7 +48,7 @@ def main():
 
     gvars = [tuple(int(a) for a in v.split(":")) for v in args.gemm_variants.split(",") if v] or [(3, 1)]
     avars = [int(v) for v in args.attn_variants.split(",") if v] or [192]
-    if args.only in ("", "gemm"):
+    if args.only in ("", "gemm", "gemmonly"):
       for (gk, gv) in gvars:
         ops.set_option("gemm_kernel", gk)
         ops.set_option("gemm_var", gv)
@@ -82,6 +82,29 @@ def main():
             del x, lin, out
       ops.set_option("gemm_kernel", 3)
       ops.set_option("gemm_var", 1)
+    if args.only in ("", "fp8", "gemm"):
+        print("== fp8 linear (quantise rows + 256x256x128 ping-pong GEMM on the scaled MFMA)", flush=True)
+        for (M, N, K, tag) in [(L, 15360, 5120, "dit qkv"), (L, 5120, 5120, "dit o/q"), (L, 13824, 5120, "ffn0"),
+                               (L, 5120, 13824, "ffn2")]:
+            x = rb(M, K)
+            lin = ops.pack_linear_fp8(rb(N, K) * (K ** -0.5), torch.zeros(N, device=dev))
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            xq = ops.quantize_fp8_rows(x)
+            ms_q = timeit(lambda: ops.quantize_fp8_rows(x), args.iters)
+            ms_g = timeit(lambda: ops.linear(xq, lin, out=out), args.iters)
+            ms = timeit(lambda: ops.linear(x, lin, out=out), args.iters)
+            tf, tfg = 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / ms_g / 1e9
+            res.append(dict(kernel="gemm_fp8", tag=tag, M=M, N=N, K=K, ms=ms, ms_gemm_only=ms_g, ms_quant=ms_q, tflops=tf,
+                            tflops_gemm_only=tfg, frac_fp8_peak=tfg / 5000))
+            print(f"fp8  {tag:14s} M={M:6d} N={N:6d} K={K:6d}  GEMM {ms_g:7.3f} ms {tfg:7.1f} TF/s ({tfg/50:4.1f}% of the fp8 peak)  "
+                  f"quant {ms_q:6.3f} ms ({M*K*3/ms_q/1e6:6.0f} GB/s)  linear {ms:7.3f} ms {tf:7.1f} TF/s", flush=True)
+            if tag in ("dit o/q", "ffn2"):
+                xs = torch.randn(M, N, device=dev)
+                gate = torch.randn(N, device=dev)
+                ms_g = timeit(lambda: ops.linear(xq, lin, g1=gate, res=xs, out_f32=True, out=xs), args.iters)
+                print(f"fp8  {tag:14s} GEMM + gate + fp32 residual in place   {ms_g:7.3f} ms {2.0*M*N*K/ms_g/1e9:7.1f} TF/s", flush=True)
+                del xs, gate
+            del x, lin, out, xq
     if args.only in ("", "attn"):
       for av in avars:
         ops.set_option("attn_var", av)
