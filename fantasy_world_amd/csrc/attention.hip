@@ -33,6 +33,11 @@ struct AttnArgs {
     float scale_log2;   // softmax scale * log2(e)
     int accumulate;
     int nqb;            // q-blocks per (batch, head)
+    // split-KV (attention_sp_kernel only; part == nullptr: off): the key range is cut into `nsplit` runs of `tiles_per_split`
+    // 64-key tiles, one work-group per (batch, head, q-block, run); a work-group writes its UN-normalised output, its row sums
+    // and its softmax shifts (fp32, [bh][qb][run][256 rows][HD + 2]) and attention_combine_kernel merges the runs.
+    float* part;
+    int nsplit, tiles_per_split;
 };
 
 template <int HD>
@@ -257,270 +262,14 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(AttnArgs p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Ping-pong attention kernel.  Same tiling, LDS images and data layout as attention_kernel above, different schedule:
-// a 64-key tile is executed as FOUR segments separated by raw s_barriers,
-//     S1  read the K tile into registers (HD/8 ds_read_b128)           S3  read the Vt tile into the SAME registers + softmax
-//     S2  QK^T: HD/8 MFMAs (+ DMA of V(t+1))                           S4  PV: HD/8 MFMAs (+ DMA of K(t+2))
-// and the two 4-wave groups of the work-group (waves w and w+4 share a SIMD) run ONE segment apart, so on every SIMD one
-// wave is in a matrix segment (fragments already in registers: MFMAs issue back to back) while its partner is in an
-// LDS/VALU segment.  K and V time-share one fragment register block, the scores of only one tile are live.
-//     slot:        4t      4t+1    4t+2    4t+3    4t+4
-//     group A:   S1(t)   S2(t)   S3(t)   S4(t)   S1(t+1)
-//     group B:   S4(t-1) S1(t)   S2(t)   S3(t)   S4(t)
-// K ring slot t&1 is last read in slot 4t+1, V ring slot t&1 in slot 4t+3; K(t+2) is requested in S4(t) (slot >= 4t+3) and
-// first read in slot 4t+8, V(t+1) in S2(t) (slot >= 4t+1 > 4t-1) and first read in slot 4t+6.  Every wave issues 2 K and 2 V
-// DMA instructions per tile (for hd < 128 with part of the lanes masked), so the waits are counted:
-//     group A: end of S2(t): vmcnt(4) -> own V(t) landed;    end of S4(t): vmcnt(4) -> own K(t+1) landed
-//     group B: end of S1(t): vmcnt(2) -> own V(t) landed;    end of S3(t): vmcnt(2) -> own K(t+1) landed
-// each before the barrier that precedes the first read of that tile by any wave (vmcnt(0) on the last tiles).
-// VAR bit 0: s_setprio(1) around the matrix segments; bit 1: deferred rescale (the running max is only raised when it
-// grows by more than 2^8 in the exponent domain: P <= 256, exact in fp32/bf16 floating point, no extra error).
-// ---------------------------------------------------------------------------------------------------------------
 #define FW_ABARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 template <int N> __device__ __forceinline__ void fw_await_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int HD, int VAR>
-__global__ __launch_bounds__(512, 2) void attention_pp_kernel(AttnArgs p) {
-    constexpr bool PRIO = (VAR & 1) != 0, DEFER = (VAR & 2) != 0;
-    constexpr int KS = HD / 16;          // k-steps of the QK^T contraction
-    constexpr int DB = HD / 32;          // 32-row blocks of O^T
-    constexpr int NCH = HD / 8;          // valid 16-B chunks per K row
-    constexpr int NFR = HD / 8;          // fragments per tile: 2*KS (K) == 4*DB (Vt)
-    constexpr int VT_TILE_BYTES = HD * 128;
-    constexpr int VROWS = HD / 16;       // Vt rows per DMA instruction (16 instructions per tile, 2 per wave)
-    constexpr int VLANES = VROWS * 8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * K_TILE_BYTES + 2 * VT_TILE_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int fi = lane & 31, hi = lane >> 5;
-
-    int item;
-    {
-        const int nwg = gridDim.x;
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int bh = item / p.nqb;
-    const int qb = item - bh * p.nqb;
-    const int b = bh / p.heads, h = bh - b * p.heads;
-
-    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
-    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
-    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
-    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
-
-    const int q_row = qb * QB + wave * 32 + fi;
-    bf16x8_t qf[KS];
-    {
-        const int qr = min(q_row, p.Lq - 1);
-        const uint16_t* src = Qp + (int64_t)qr * p.ldq + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(src + ks * 16);
-    }
-
-    const int nt = (p.Lk + KVB - 1) / KVB;
-    const bool ragged = (p.Lk & (KVB - 1)) != 0;
-
-    // ---- DMA addressing: uniform tile base (SGPR) + per-lane unsigned byte offset -------------------------------------
-    // K tile: 16 pieces of 4 rows x 256 B; wave w issues pieces w and w+8.  lane -> row = 4*pc + lane/16, physical chunk
-    // = lane%16, logical chunk = phys ^ (row&15) (lanes whose logical chunk is beyond the head are masked off).
-    unsigned koff[2], koffl[2];
-    bool kvalid[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave + 8 * i) * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ (row & 15);
-        kvalid[i] = chunk < NCH;
-        koff[i] = (unsigned)(row * (int)p.ldk + chunk * 8) * 2u;
-        const int rl = min(row, p.Lk - 1 - (nt - 1) * KVB);           // last (possibly ragged) tile: clamp to the last key
-        koffl[i] = (unsigned)(rl * (int)p.ldk + chunk * 8) * 2u;
-    }
-    // Vt tile: 16 instructions of VROWS rows x 128 B; wave w issues instructions 2w and 2w+1 (lanes >= VLANES masked off).
-    unsigned voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int d = min((wave * 2 + i) * VROWS + (lane >> 3), HD - 1);
-        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
-        voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
-    }
-    const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
-    auto issue_k = [&](int slot, int t) {
-        const char* kt = Kp + (size_t)t * k_tile_stride;
-        char* k_lds = smem + slot * K_TILE_BYTES;
-        const bool last = ragged && t == nt - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned off = last ? koffl[i] : koff[i];
-            if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + 8 * i) * 1024);
-        }
-    };
-    auto issue_v = [&](int slot, int t) {
-        const char* vt = Vp + (size_t)t * (KVB * 2);
-        char* v_lds = smem + 2 * K_TILE_BYTES + slot * VT_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave * 2 + i) * (VROWS * 128));
-    };
-
-    int kcoff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
-    int vcoff[4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) vcoff[s2] = 2 * K_TILE_BYTES + fi * 128 + (((2 * s2 + hi) ^ ((fi >> 1) & 7)) << 4);
-
-    f32x16_t o[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;
-    const float c = p.scale_log2;
-    bf16x8_t fr[NFR];
-    f32x16_t s0, s1;
-    uint32_t pw[16];
-
-    issue_k(0, 0);
-    issue_v(0, 0);
-    if (nt > 1) issue_k(1, 1);
-    fw_await_vm<0>();
-    FW_ABARRIER();
-    if (grp == 1) FW_ABARRIER();
-
-    for (int t = 0; t < nt; ++t) {
-        const bool has1 = t + 1 < nt, has2 = t + 2 < nt;
-        // ------------------------------------------------------------ S1: K fragments -> registers
-        {
-            const char* kb = smem + (t & 1) * K_TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                fr[2 * ks] = *(const bf16x8_t*)(kb + kcoff[ks]);
-                fr[2 * ks + 1] = *(const bf16x8_t*)(kb + 32 * 256 + kcoff[ks]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 1) { if (has1) fw_await_vm<2>(); else fw_await_vm<0>(); }
-        FW_ABARRIER();
-        // ------------------------------------------------------------ S2: S^T = K Q^T (+ DMA of V(t+1))
-        if (has1) issue_v((t + 1) & 1, t + 1);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) { if (has1) fw_await_vm<4>(); else fw_await_vm<0>(); }
-        FW_ABARRIER();
-        // ------------------------------------------------------------ S3: Vt fragments -> registers, online softmax
-        {
-            const char* vb = smem + (t & 1) * VT_TILE_BYTES;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int d = 0; d < DB; ++d) fr[s2 * DB + d] = *(const bf16x8_t*)(vb + d * 32 * 128 + vcoff[s2]);
-        }
-        if (ragged && t == nt - 1) {
-            const int kbase = t * KVB + 4 * hi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = kbase + (r & 3) + 8 * (r >> 2);
-                if (kk >= p.Lk) s0[r] = -1.0e30f;
-                if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
-            }
-        }
-        {
-            float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-            {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            const bool need = DEFER ? ((mx - m_run) * c > 8.0f) : (mx > m_run);
-            if (__any(need)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-                m_run = m_new;
-            }
-            const float mc = m_run * c;
-            float ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-                const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
-                const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-                const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
-                ls += (a0 + a1) + (b0 + b1);
-                pw[r >> 1] = pack_bf16x2(a0, a1);
-                pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
-            }
-            l_run += ls;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 1) { if (has1) fw_await_vm<2>(); else fw_await_vm<0>(); }
-        FW_ABARRIER();
-        // ------------------------------------------------------------ S4: O^T += Vt P^T (+ DMA of K(t+2))
-        if (has2) issue_k(t & 1, t + 2);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            u32x4_t pv4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
-            bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
-#pragma unroll
-            for (int d = 0; d < DB; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s2 * DB + d], pf, o[d], 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) { if (has2) fw_await_vm<4>(); else fw_await_vm<0>(); }
-        FW_ABARRIER();
-    }
-    if (grp == 0) FW_ABARRIER();
-
-    // ---- epilogue: O[q][d] = O^T[d][q] / l --------------------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row < p.Lq) {
-        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = d * 32 + 8 * g + 4 * hi;
-                float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
-                float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
-                u32x2_t* ptr = (u32x2_t*)(dst + col);
-                if (p.accumulate) {
-                    const u32x2_t old = *ptr;
-                    v0 += __uint_as_float(old[0] << 16);
-                    v1 += __uint_as_float(old[0] & 0xffff0000u);
-                    v2 += __uint_as_float(old[1] << 16);
-                    v3 += __uint_as_float(old[1] & 0xffff0000u);
-                }
-                u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                *ptr = w;
-            }
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// Ping-pong attention, TWO segments per tile (the schedule the PMC counters asked for).
+// Two-segment ping-pong schedule (attention_pp3_kernel below; round 1's four-segment and first two-segment kernels were
+// removed in round 2 -- their measurements are kept here because they are why the schedule looks the way it does).
 //
-// Measured on attention_pp_kernel (rocprofv3 PMC, profiles/r01): ~226 VALU instructions and ~1400 active cycles per
+// Measured on the four-segment kernel (rocprofv3 PMC, profiles/r01): ~226 VALU instructions and ~1400 active cycles per
 // wave-tile against 1024 cycles of MFMA; with four segments per tile the softmax segment (~1400 cycles) was paired with a
 // 512-cycle matrix segment twice per tile, i.e. tile time = 1024 + 2 x 1400: VALU and MFMA time ADD instead of overlapping
 // (53 % matrix-pipe utilisation at the real 1.9 GHz clock).  Here a wave alternates only two segments,
@@ -568,277 +317,9 @@ constexpr int ARING = 4;
 __device__ unsigned long long g_attn_ts[8 * 8];
 #define FW_TS(K) do { if (TIMING && blockIdx.x == 0 && t == 100 && lane == 0) g_attn_ts[wave * 8 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <int HD, int VAR>
-__global__ __launch_bounds__(512, 2) void attention_pp2_kernel(AttnArgs p) {
-    constexpr bool PRIO = (VAR & 1) != 0, PIN = (VAR & 2) != 0;
-    constexpr bool DMA_V = (VAR & 4) != 0;    // issue the tile DMA from the V segment (K(t+3), V(t+3)) instead of from MM (K(t+4), V(t+3))
-    constexpr bool DMA_QK = (VAR & 8) != 0;   // issue it between the QK^T MFMAs instead of in front of the PV MFMAs
-    constexpr int KS = HD / 16, DB = HD / 32, NCH = HD / 8, NFR = HD / 8;
-    constexpr int VT_TILE_BYTES = HD * 128;
-    constexpr int VROWS = HD / 16, VLANES = VROWS * 8;
-    constexpr int V_BASE = ARING * K_TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[ARING * K_TILE_BYTES + ARING * VT_TILE_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int fi = lane & 31, hi = lane >> 5;
-
-    int item;
-    {
-        const int nwg = gridDim.x;
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int bh = item / p.nqb;
-    const int qb = item - bh * p.nqb;
-    const int b = bh / p.heads, h = bh - b * p.heads;
-
-    const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
-    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
-    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
-    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
-
-    const int q_row = qb * QB + wave * 32 + fi;
-    bf16x8_t qf[KS];
-    {
-        const int qr = min(q_row, p.Lq - 1);
-        const uint16_t* src = Qp + (int64_t)qr * p.ldq + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(src + ks * 16);
-    }
-
-    const int nt = (p.Lk + KVB - 1) / KVB;
-    const bool ragged = (p.Lk & (KVB - 1)) != 0;
-
-    unsigned koff[2], koffl[2];
-    bool kvalid[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave + 8 * i) * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ (row & 15);
-        kvalid[i] = chunk < NCH;
-        koff[i] = (unsigned)(row * (int)p.ldk + chunk * 8) * 2u;
-        const int rl = min(row, p.Lk - 1 - (nt - 1) * KVB);
-        koffl[i] = (unsigned)(rl * (int)p.ldk + chunk * 8) * 2u;
-    }
-    unsigned voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int d = min((wave * 2 + i) * VROWS + (lane >> 3), HD - 1);
-        const int chunk = (lane & 7) ^ ((d >> 1) & 7);
-        voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
-    }
-    const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
-    auto issue_k = [&](int t) {                 // K(t) -> ring slot t & 3 (2 DMA instructions per wave)
-        const char* kt = Kp + (size_t)t * k_tile_stride;
-        char* k_lds = smem + (t & (ARING - 1)) * K_TILE_BYTES;
-        const bool last = ragged && t == nt - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned off = last ? koffl[i] : koff[i];
-            if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + 8 * i) * 1024);
-        }
-    };
-    auto issue_v = [&](int t) {                 // Vt(t) -> ring slot t & 3 (2 DMA instructions per wave)
-        const char* vt = Vp + (size_t)t * (KVB * 2);
-        char* v_lds = smem + V_BASE + (t & (ARING - 1)) * VT_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave * 2 + i) * (VROWS * 128));
-    };
-
-    int kcoff[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
-    int vcoff[4];
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) vcoff[s2] = V_BASE + fi * 128 + (((2 * s2 + hi) ^ ((fi >> 1) & 7)) << 4);
-
-    f32x16_t o[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -1.0e30f, l_run = 0.f;
-    const float c = p.scale_log2;
-    bf16x8_t fr[NFR];
-    f32x16_t s0, s1;
-    uint32_t pw[16];
-
-    // ---- prologue: K(0) | K(1) V(0) | K(2) V(1) | K(3) V(2), then S(0) = K(0) Q^T by every wave ------------------------
-    issue_k(0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (j + 1 < nt && (!DMA_V || j < 2)) issue_k(j + 1);
-        if (j < nt) issue_v(j);
-    }
-    fw_await_vm<0>();
-    FW_ABARRIER();
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        fr[2 * ks] = *(const bf16x8_t*)(smem + kcoff[ks]);
-        fr[2 * ks + 1] = *(const bf16x8_t*)(smem + 32 * 256 + kcoff[ks]);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
-    }
-    if (grp == 1) FW_ABARRIER();
-
-    int t = 0;
-    auto tile = [&](auto has1_tag) {
-        constexpr bool has1 = decltype(has1_tag)::value;
-        const bool steady = DMA_V ? (t + 3 < nt) : (t + 4 < nt);
-        // ------------------------------------------------------------ V(t): Vt fragments -> registers, online softmax
-        {
-            const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int d = 0; d < DB; ++d) fr[s2 * DB + d] = *(const bf16x8_t*)(vb + d * 32 * 128 + vcoff[s2]);
-        }
-        if (DMA_V && t + 3 < nt) { issue_k(t + 3); issue_v(t + 3); }
-        if (ragged && t == nt - 1) {
-            const int kbase = t * KVB + 4 * hi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = kbase + (r & 3) + 8 * (r >> 2);
-                if (kk >= p.Lk) s0[r] = -1.0e30f;
-                if (kk + 32 >= p.Lk) s1[r] = -1.0e30f;
-            }
-        }
-        {
-            float mx = fw_max16(s0);
-            mx = fmaxf(mx, fw_max16(s1));
-            {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            if (__any((mx - m_run) * c > 8.0f)) {
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-                l_run *= alpha;
-#pragma unroll
-                for (int d = 0; d < DB; ++d)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-                m_run = m_new;
-            }
-            const float mc = m_run * c;
-            float ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float a0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-                const float a1 = __builtin_amdgcn_exp2f(fmaf(s0[r + 1], c, -mc));
-                const float b0 = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
-                const float b1 = __builtin_amdgcn_exp2f(fmaf(s1[r + 1], c, -mc));
-                ls += (a0 + a1) + (b0 + b1);
-                pw[r >> 1] = pack_bf16x2(a0, a1);
-                pw[8 + (r >> 1)] = pack_bf16x2(b0, b1);
-            }
-            l_run += ls;
-        }
-        if (PIN) {   // keep the exponentials and the row sum in THIS segment (LLVM otherwise sinks them behind the barrier, next to
-                     // the PV MFMAs, and keeps all 32 probabilities alive for a serial add chain at the end of MM)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pw[i]));
-            asm volatile("" : "+v"(l_run));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!steady) fw_await_vm<0>();
-        else if (DMA_V) { if (grp == 0) fw_await_vm<10>(); else fw_await_vm<8>(); }
-        else { if (grp == 0) fw_await_vm<10>(); else fw_await_vm<4>(); }
-        FW_ABARRIER();
-        // ------------------------------------------------------------ MM(t): PV(t), K(t+1) fragments, QK^T(t+1)
-        if (!DMA_V && !DMA_QK) {
-            if (t + 4 < nt) issue_k(t + 4);
-            if (t + 3 < nt) issue_v(t + 3);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        const char* kb = smem + ((t + 1) & (ARING - 1)) * K_TILE_BYTES;
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            u32x4_t pv4 = {pw[4 * s2], pw[4 * s2 + 1], pw[4 * s2 + 2], pw[4 * s2 + 3]};
-            bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pv4);
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                const int i = s2 * DB + d;
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf, o[d], 0, 0, 0);
-                // fragment register i is free now: refill it with K(t+1) fragment i (key block i&1, k-step i>>1)
-                if (has1) fr[i] = *(const bf16x8_t*)(kb + (i & 1) * 32 * 256 + kcoff[i >> 1]);
-            }
-        }
-        if (has1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
-                if (DMA_QK && !DMA_V) {
-                    if (ks == 0 && t + 4 < nt) issue_k(t + 4);
-                    if (ks == KS / 2 && t + 3 < nt) issue_v(t + 3);
-                }
-            }
-        }
-        if (has1 && !(DMA_QK && !DMA_V)) {
-            // pin the issue order: PV MFMA i, then the ds_read that refills its fragment register, ..., then the QK^T MFMAs
-            // (left alone, the scheduler postpones every read behind the 16 PV MFMAs and then waits on each pair)
-#pragma unroll
-            for (int i = 0; i < NFR; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NFR, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!steady) fw_await_vm<0>();
-        else if (DMA_V) { if (grp == 0) fw_await_vm<8>(); else fw_await_vm<6>(); }
-        else { if (grp == 0) fw_await_vm<8>(); else fw_await_vm<10>(); }
-        FW_ABARRIER();
-    };
-    for (; t < nt - 1; ++t) tile(std::true_type{});
-    tile(std::false_type{});
-    if (grp == 0) FW_ABARRIER();
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row < p.Lq) {
-        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
-#pragma unroll
-        for (int d = 0; d < DB; ++d) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = d * 32 + 8 * g + 4 * hi;
-                float v0 = o[d][4 * g + 0] * inv, v1 = o[d][4 * g + 1] * inv;
-                float v2 = o[d][4 * g + 2] * inv, v3 = o[d][4 * g + 3] * inv;
-                u32x2_t* ptr = (u32x2_t*)(dst + col);
-                if (p.accumulate) {
-                    const u32x2_t old = *ptr;
-                    v0 += __uint_as_float(old[0] << 16);
-                    v1 += __uint_as_float(old[0] & 0xffff0000u);
-                    v2 += __uint_as_float(old[1] << 16);
-                    v3 += __uint_as_float(old[1] & 0xffff0000u);
-                }
-                u32x2_t w = {pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-                *ptr = w;
-            }
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// attention_pp3_kernel: the two-segment ping-pong schedule of attention_pp2_kernel with the softmax cut down to what the
-// issue slots allow.  Measured (pp2 variants, hd 128 vs 64): slot time ~ V-segment + 0.8 x MM-segment, i.e. VALU work of
+// attention_pp3_kernel: the two-segment ping-pong schedule above with the softmax cut down to what the
+// issue slots allow.  Measured (round-1 two-segment variants, hd 128 vs 64): slot time ~ V-segment + 0.8 x MM-segment, i.e. VALU work of
 // one wave hardly overlaps the MFMAs of its SIMD partner -- every instruction of either wave costs an issue slot of the
 // shared SIMD, so the lever is the instruction COUNT per tile.  Requires FW_ATTN_Q_PRESCALED (scores arrive in the log2
 // domain).  Per 64-key tile and lane:
@@ -1219,13 +700,17 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         const int q = nwg >> 3, r = nwg & 7;
         item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
+    int run = 0;
+    if (p.part) { run = item % p.nsplit; item /= p.nsplit; }
     const int bh = item / p.nqb;
     const int qb = item - bh * p.nqb;
     const int b = bh / p.heads, h = bh - b * p.heads;
+    const int key0 = run * p.tiles_per_split * KVB;                                  // first key of this run (0 without split-KV)
+    const int Lk = p.part ? min(p.Lk - key0, p.tiles_per_split * KVB) : p.Lk;       // keys this work-group attends to
 
     const uint16_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
-    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD);
-    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp);
+    const char* Kp = (const char*)(p.K + (int64_t)b * p.bsk + (int64_t)h * HD + (int64_t)key0 * p.ldk);
+    const char* Vp = (const char*)(p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp + key0);
     uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
 
     bf16x8_t qf[NS][KS];
@@ -1244,8 +729,8 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(qf[sb][ks]));
     }
-    const int nt = (p.Lk + KVB - 1) / KVB;
-    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+    const int nt = (Lk + KVB - 1) / KVB;
+    const bool ragged = (Lk & (KVB - 1)) != 0;
 
     // tile DMA: a K tile is 16 pieces of 4 key rows, a Vt tile 16 pieces of HD/16 feature rows; wave w requests pieces w + NW*i
     unsigned koff[NP];
@@ -1274,7 +759,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
             unsigned off = koff[i];
             if (last) {
                 const int row = (wave + NW * i) * 4 + (lane >> 4);
-                const int over = row - (p.Lk - 1 - (nt - 1) * KVB);
+                const int over = row - (Lk - 1 - (nt - 1) * KVB);
                 if (over > 0) off -= (unsigned)(over * (int)p.ldk) * 2u;
             }
             if (kvalid[i]) FW_GLDS16(kt + off, k_lds + (wave + NW * i) * 1024);
@@ -1342,7 +827,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
                 for (int sb = 0; sb < NS; ++sb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (kbase + (r & 3) + 8 * (r >> 2) >= p.Lk) cur[sb][r] = -1.0e30f;
+                        if (kbase + (r & 3) + 8 * (r >> 2) >= Lk) cur[sb][r] = -1.0e30f;
             }
         }
         const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
@@ -1468,7 +953,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         if (ragged && nt == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (4 * hi + (r & 3) + 8 * (r >> 2) >= p.Lk) sA[sb][r] = -1.0e30f;
+                if (4 * hi + (r & 3) + 8 * (r >> 2) >= Lk) sA[sb][r] = -1.0e30f;
         }
         float mx = fw_max16(sA[sb]);
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
@@ -1534,11 +1019,11 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
             bf16x8_t qe[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qe[ks] = sb == 0 ? qf[0][ks] : qf[NS - 1][ks];
-            for (int kb0 = 0; kb0 < p.Lk; kb0 += 32) {
+            for (int kb0 = 0; kb0 < Lk; kb0 += 32) {
                 f32x16_t sc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-                const int krow = min(kb0 + fi, p.Lk - 1);
+                const int krow = min(kb0 + fi, Lk - 1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(Kg + (size_t)krow * p.ldk + ks * 16 + hi * 8);
@@ -1546,7 +1031,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (kb0 + 4 * hi + (r & 3) + 8 * (r >> 2) >= p.Lk) sc[r] = -3.0e38f;
+                    if (kb0 + 4 * hi + (r & 3) + 8 * (r >> 2) >= Lk) sc[r] = -3.0e38f;
                 float mx = fw_max16(sc);
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                 mx = fmaxf(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])), me);
@@ -1580,14 +1065,33 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
 #pragma unroll
                 for (int d = 0; d < DB; ++d) o[0][d] = oe[d];
                 l_run[0] = le;
+                m_run[0] = me;
             } else {
 #pragma unroll
                 for (int d = 0; d < DB; ++d) o[NS - 1][d] = oe[d];
                 l_run[NS - 1] = le;
+                m_run[NS - 1] = me;
             }
         }
     }
 
+    if (p.part) {
+        // split-KV: un-normalised O^T, row sum and shift of this run; rows beyond Lq are written too (never read back)
+#pragma unroll
+        for (int sb = 0; sb < NS; ++sb) {
+            const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
+            float* dst = p.part + ((((int64_t)bh * p.nqb + qb) * p.nsplit + run) * QB + (wave * NS + sb) * 32 + fi) * (HD + 2);
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4_t v = {o[sb][d][4 * g + 0], o[sb][d][4 * g + 1], o[sb][d][4 * g + 2], o[sb][d][4 * g + 3]};
+                    *(f32x4_t*)(dst + d * 32 + 8 * g + 4 * hi) = v;
+                }
+            if (hi == 0) { dst[HD] = l_tot; dst[HD + 1] = m_run[sb]; }
+        }
+        return;
+    }
 #pragma unroll
     for (int sb = 0; sb < NS; ++sb) {
         const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
@@ -1615,6 +1119,50 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
                 }
             }
         }
+    }
+}
+
+// Merge of the split-KV runs: out[row] = sum_c O_c 2^(m_c - M) / sum_c l_c 2^(m_c - M), M = max_c m_c (all in the log2 domain the
+// kernels work in).  One wave per (batch, head, q-block, row); lane = 2 or 4 consecutive features.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_combine_kernel(AttnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t witem = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t rows_total = (int64_t)p.batch * p.heads * p.nqb * QB;
+    if (witem >= rows_total) return;
+    const int row_in = (int)(witem % QB);
+    const int64_t blk = witem / QB;                     // (bh * nqb + qb)
+    const int qb = (int)(blk % p.nqb);
+    const int bh = (int)(blk / p.nqb);
+    const int q_row = qb * QB + row_in;
+    if (q_row >= p.Lq) return;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const float* base = p.part + (blk * p.nsplit * QB + row_in) * (HD + 2);
+    const int64_t run_stride = (int64_t)QB * (HD + 2);
+    float M = -3.0e38f;
+    for (int c = 0; c < p.nsplit; ++c) M = fmaxf(M, base[c * run_stride + HD + 1]);
+    constexpr int PER = HD / 64 + (HD % 64 ? 1 : 0);    // features per lane: 2 (hd 128), 2 (hd 96: 48 lanes active), 1 (hd 64)
+    constexpr int W = HD == 64 ? 1 : 2;
+    const int f0 = lane * W;
+    if (f0 >= HD) return;
+    float acc[W], L = 0.f;
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc[j] = 0.f;
+    for (int c = 0; c < p.nsplit; ++c) {
+        const float* src = base + c * run_stride;
+        const float wgt = __builtin_amdgcn_exp2f(fmaxf(src[HD + 1] - M, -200.f));
+        L += src[HD] * wgt;
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[j] += src[f0 + j] * wgt;
+    }
+    (void)PER;
+    const float inv = 1.0f / L;
+    uint16_t* dst = p.O + (int64_t)b * p.bso + (int64_t)h * HD + (int64_t)q_row * p.ldo + f0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        float v = acc[j] * inv;
+        if (p.accumulate) v += bf16_bits_to_f32(dst[j]);
+        dst[j] = f32_to_bf16_bits(v);
     }
 }
 
@@ -1667,12 +1215,26 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
 
 }  // namespace
 
+// Bytes of workspace with which fw_attention_bf16 takes the split-KV route for the tail q-block; 0 = it would not use one.
+extern "C" int64_t fw_attention_workspace_bytes(int batch, int heads, int head_dim, int Lq, int Lk) {
+    if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return 0;
+    const int tail = Lq % QB, nqb_full = Lq / QB;
+    const int64_t w_full = (int64_t)nqb_full * heads * batch, w_all = w_full + (int64_t)heads * batch;
+    const int nt = (Lk + KVB - 1) / KVB;
+    if (tail == 0 || nqb_full == 0 || nt < 16 || heads * batch > 128) return 0;
+    if ((w_full + 255) / 256 >= (w_all + 255) / 256) return 0;                 // the tail work-groups fit the last round anyway
+    const int target = max(2, min(16, 256 / (heads * batch)));
+    const int tps = (nt + target - 1) / target;
+    const int nsplit = (nt + tps - 1) / tps;
+    return (int64_t)batch * heads * nsplit * QB * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
 extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
                                  const uint16_t* K, int64_t ldk, int64_t bsk,
                                  const uint16_t* Vt, int64_t Lk_pad,
                                  uint16_t* O, int64_t ldo, int64_t bso,
                                  int batch, int heads, int head_dim, int Lq, int Lk,
-                                 float scale, int flags, void* stream) {
+                                 float scale, int flags, void* workspace, int64_t workspace_bytes, void* stream) {
     if (batch <= 0 || heads <= 0 || Lq <= 0) return 0;
     if (Lk <= 0) { fw_set_error("fw_attention_bf16: Lk must be > 0"); return FW_E_BADARG; }
     if (head_dim != 64 && head_dim != 96 && head_dim != 128) { fw_set_error("fw_attention_bf16: head_dim must be 64, 96 or 128"); return FW_E_UNSUPPORTED; }
@@ -1685,74 +1247,62 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     const bool prescaled = (flags & FW_ATTN_Q_PRESCALED) != 0;
     p.scale_log2 = prescaled ? 1.0f : scale * 1.4426950408889634f; p.accumulate = (flags & FW_ATTN_ACCUMULATE) ? 1 : 0;
     p.nqb = (Lq + QB - 1) / QB;
+    p.part = nullptr; p.nsplit = 1; p.tiles_per_split = 0;
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
-    int var = fw_get_option(FW_OPT_ATTN_VAR);           // 0 = first kernel; 16 + bits = ping-pong kernel (bit 0 prio, bit 1 deferred rescale)
+    // Tail q-block (Lq % 256 != 0) that would cost the grid a whole extra round of the 256 CUs (one work-group per CU): its rows
+    // go through split-KV instead -- the full q-blocks in one launch (whole rounds), then the tail rows with the keys cut into
+    // runs (heads * batch * nsplit short work-groups side by side), then the merge.  L2 = 32865 = 128 x 256 + 97 query rows:
+    // bicross direction 2 (12 heads) 1548 work-groups = 6.05 rounds -> 6 + 1/16; VGGT global (16 heads) 2064 = 8.06 -> 8 + 1/16.
+    if (workspace != nullptr && prescaled) {
+        int nsplit = 0, tps = 0;
+        const int64_t need = fw_attention_workspace_bytes(batch, heads, head_dim, Lq, Lk);
+        if (need > 0 && workspace_bytes >= need) {
+            const int nt = (Lk + KVB - 1) / KVB;
+            const int target = max(2, min(16, 256 / (heads * batch)));
+            tps = (nt + target - 1) / target;
+            nsplit = (nt + tps - 1) / tps;
+            const int Lq_main = (Lq / QB) * QB;
+            int rc = fw_attention_bf16(Q, ldq, bsq, K, ldk, bsk, Vt, Lk_pad, O, ldo, bso, batch, heads, head_dim, Lq_main, Lk,
+                                       scale, flags, nullptr, 0, stream);
+            if (rc) return rc;
+            AttnArgs t = p;
+            t.Q = Q + (int64_t)Lq_main * ldq; t.O = O + (int64_t)Lq_main * ldo;
+            t.Lq = Lq - Lq_main; t.nqb = 1;
+            t.part = (float*)workspace; t.nsplit = nsplit; t.tiles_per_split = tps;
+            const unsigned g = (unsigned)(heads * batch * nsplit);
+            if (head_dim == 128) hipLaunchKernelGGL((attention_sp_kernel<128, 1>), dim3(g), dim3(512), 0, st, t);
+            else if (head_dim == 96) hipLaunchKernelGGL((attention_sp_kernel<96, 1>), dim3(g), dim3(512), 0, st, t);
+            else hipLaunchKernelGGL((attention_sp_kernel<64, 1>), dim3(g), dim3(512), 0, st, t);
+            const unsigned cg = (unsigned)((int64_t)batch * heads * QB + 3) / 4;
+            if (head_dim == 128) hipLaunchKernelGGL(attention_combine_kernel<128>, dim3(cg), dim3(256), 0, st, t);
+            else if (head_dim == 96) hipLaunchKernelGGL(attention_combine_kernel<96>, dim3(cg), dim3(256), 0, st, t);
+            else hipLaunchKernelGGL(attention_combine_kernel<64>, dim3(cg), dim3(256), 0, st, t);
+            return (int)hipGetLastError();
+        }
+    }
+    int var = fw_get_option(FW_OPT_ATTN_VAR);           // 0 = first kernel (generic); 64.. = two-segment ping-pong; 128.. = single stream
     // 192 = per-head-dim choice among the pre-scaled kernels (microbench, profiles/r01/attention_sp_ablation.txt): the
     // single-stream kernel for hd 128 and hd 64, the two-segment ping-pong for hd 96
     if (var == 192) var = head_dim == 96 ? 64 : 129;
     if (prescaled && var >= 128) {
-        // single-stream software pipeline on half tiles; bit 0: pinned issue order, bit 1: one 64-row wave per SIMD
+        // single-stream software pipeline on half tiles, pinned issue order; bit 1: one 64-row wave per SIMD (4 waves)
 #define FW_ATTN_SP(HDV, V) \
     hipLaunchKernelGGL((attention_sp_kernel<HDV, V>), dim3((unsigned)nwg), dim3(((V) & 2) ? 256 : 512), 0, st, p)
 #define FW_ATTN_SP_HD(V) \
     do { if (head_dim == 128) FW_ATTN_SP(128, V); else if (head_dim == 96) FW_ATTN_SP(96, V); else FW_ATTN_SP(64, V); } while (0)
-        if (var >= 256 && head_dim == 128) {      // timing ablations of the 64-row variant (see the kernel's AB_ flags)
-            switch ((var - 256) & 0x7c) {
-                case 4: FW_ATTN_SP(128, 3 + 4); break;
-                case 8: FW_ATTN_SP(128, 3 + 8); break;
-                case 16: FW_ATTN_SP(128, 3 + 16); break;
-                case 28: FW_ATTN_SP(128, 3 + 28); break;
-                case 32: FW_ATTN_SP(128, 3 + 32); break;
-                default: FW_ATTN_SP(128, 3); break;
-            }
-            return (int)hipGetLastError();
-        }
-        if (var >= 160 && var < 192) {            // two tiles per barrier
-            if (var & 2) FW_ATTN_SP_HD(128 + 3); else FW_ATTN_SP_HD(128 + 1);
-            return (int)hipGetLastError();
-        }
-        switch (var & 3) {
-            case 0: FW_ATTN_SP_HD(0); break;
-            case 1: FW_ATTN_SP_HD(1); break;
-            case 2: FW_ATTN_SP_HD(2); break;
-            default: FW_ATTN_SP_HD(3); break;
-        }
+        if (var & 2) FW_ATTN_SP_HD(3); else FW_ATTN_SP_HD(1);
         return (int)hipGetLastError();
     }
     if (prescaled && var >= 64) {
-        // fast path: log2-domain scores (var 64: DMA in front of PV, 65: DMA between the QK^T MFMAs)
+        // two-segment ping-pong on log2-domain scores; bit 1: TIMING build (tools/attn_timeline.py)
 #define FW_ATTN_PP3(HDV, V) hipLaunchKernelGGL((attention_pp3_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
-        if ((var & 7) == 4) { if (head_dim == 128) FW_ATTN_PP3(128, 4); else if (head_dim == 96) FW_ATTN_PP3(96, 4); else FW_ATTN_PP3(64, 4); }
-        else if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
-        else if (var & 1) { if (head_dim == 128) FW_ATTN_PP3(128, 1); else if (head_dim == 96) FW_ATTN_PP3(96, 1); else FW_ATTN_PP3(64, 1); }
+        if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
         else { if (head_dim == 128) FW_ATTN_PP3(128, 0); else if (head_dim == 96) FW_ATTN_PP3(96, 0); else FW_ATTN_PP3(64, 0); }
         return (int)hipGetLastError();
     }
-    if (var >= 32) {
-#define FW_ATTN_PP2(HDV, V) hipLaunchKernelGGL((attention_pp2_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
-#define FW_ATTN_PP2_HD(V) do { if (head_dim == 128) FW_ATTN_PP2(128, V); else if (head_dim == 96) FW_ATTN_PP2(96, V); else FW_ATTN_PP2(64, V); } while (0)
-        switch (var & 15) {
-            case 3: FW_ATTN_PP2_HD(3); break;
-            case 6: FW_ATTN_PP2_HD(6); break;
-            case 7: FW_ATTN_PP2_HD(7); break;
-            case 10: FW_ATTN_PP2_HD(10); break;
-            default: FW_ATTN_PP2_HD(2); break;
-        }
-        return (int)hipGetLastError();
-    }
-    if (var >= 16) {
-#define FW_ATTN_PP(HDV, V) hipLaunchKernelGGL((attention_pp_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
-#define FW_ATTN_PP_HD(V) do { if (head_dim == 128) FW_ATTN_PP(128, V); else if (head_dim == 96) FW_ATTN_PP(96, V); else FW_ATTN_PP(64, V); } while (0)
-        switch (var & 3) {
-            case 0: FW_ATTN_PP_HD(0); break;
-            case 1: FW_ATTN_PP_HD(1); break;
-            case 2: FW_ATTN_PP_HD(2); break;
-            default: FW_ATTN_PP_HD(3); break;
-        }
-        return (int)hipGetLastError();
-    }
+    // q not pre-scaled (callers that cannot fold scale * log2(e) into q), or FW_ATTN_VAR = 0: the generic first kernel
     if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, dim3((unsigned)nwg), dim3(512), 0, st, p);
     else if (head_dim == 96) hipLaunchKernelGGL(attention_kernel<96>, dim3((unsigned)nwg), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(attention_kernel<64>, dim3((unsigned)nwg), dim3(512), 0, st, p);

@@ -1,13 +1,17 @@
 // bf16 MFMA GEMM with fused epilogue for gfx950:  C = epi(A[M,K] * W[N,K]^T)
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as 2x2 v_mfma_f32_32x32x16_bf16
-// accumulators.  A and W k-slabs are streamed HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round
-// trip), two LDS stages, one barrier per k-slab.  LDS rows are 128 B (64 bf16); the 16-byte chunk index is
-// XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads of a 16-lane service group hit 16
-// distinct 16-B slots of the 256-B bank row (conflict free).  Because global_load_lds writes lane-linear,
-// the swizzle is applied to the per-lane SOURCE address and again on the read (both sides or neither).
-// Work-group ids are remapped so each XCD (private L2) owns a contiguous range of tiles, grouped 8 M-tiles
-// deep so concurrently resident tiles share A bands and W panels in L2.
+// Three kernels (round 1 carried six; the superseded generations -- first 2-stage staggered kernel, 5-deep half-slab ring,
+// compiler-ordered four-wave kernel, first ping-pong kernel -- were removed in round 2, their numbers are in DESIGN.md section 4):
+//   gemm_bf16_pp2_kernel   256x256x64, 8 waves in two groups running LOAD || MFMA ping-pong: every big token-major GEMM (default)
+//   gemm_bf16_w4b_kernel   256x256x64, 4 waves with 128x128 wave tiles, hand-ordered single instruction stream: GEMMs with a short
+//                          K (<= 1280: VGGT qkv / fc1, bicross output projections), and the INDEPENDENT implementation the
+//                          full-size agreement test compares the default path with (FW_GEMM_KERNEL=5 forces it everywhere)
+//   gemm_bf16_kernel       128x128x64, 4 waves: small / ragged shapes and the <= 128-row M tail of the big ones
+// All stream A and W k-slabs HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip).  LDS rows are 128 B (64 bf16); the
+// 16-byte chunk index is XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads of a 16-lane service group hit 16
+// distinct 16-B slots of the 256-B bank row (conflict free).  Because global_load_lds writes lane-linear, the swizzle is applied
+// to the per-lane SOURCE address and again on the read (both sides or neither).  Work-group ids are remapped so each XCD
+// (private L2) owns a contiguous range of tiles, grouped 8 M-tiles deep so concurrently resident tiles share A bands and W panels.
 #include "fw_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -240,355 +244,14 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 256x256x64 tile, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 accumulators of 32x32.  One work-group per CU, so the
-// two waves that share a SIMD belong to the SAME work-group; to keep the matrix pipe fed they are run half a phase
-// apart: waves 0-3 (group A) and 4-7 (group B) execute the same sequence of  [LOAD fragments | barrier | 16 MFMA |
-// barrier]  phases, but group B takes one extra barrier at the start (and group A one at the end), so that while one
-// wave of a SIMD is in its MFMA segment its partner is in its LDS-read segment.  A k-slab is consumed in two phases
-// (wave rows 0-63, then 64-127; the B fragments are read once per slab).  The next slab is streamed with
-// global_load_lds during the phases in which its LDS stage is provably idle, and waited for (vmcnt(0)) one barrier
-// before its first read:
-//     global slot:      4t      4t+1      4t+2      4t+3      4t+4
-//     group A:        LOAD(t,0) MFMA(t,0) LOAD(t,1) MFMA(t,1) LOAD(t+1,0)
-//     group B:        MFMA(..)  LOAD(t,0) MFMA(t,0) LOAD(t,1) MFMA(t,1)
-//     slab t+1 DMA:   A: 1/2    B: all    A: 1/2    wait      first read (A)   -- last read of slab t-1 completes
-//                                                                                  before the barrier ending slot 4t-1
-// Barriers are raw s_barrier (inline asm): a __syncthreads() would drain the DMA queue at every barrier.
-// ---------------------------------------------------------------------------------------------------------------
 constexpr int TM = 256, TN = 256;
 constexpr int STAGE2 = (TM + TN) * BK * 2;   // 64 KiB
 
+// Barriers are raw s_barrier (inline asm): a __syncthreads() would drain the DMA queue (vmcnt(0)) at every barrier.
 #define FW_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define FW_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-template <int VAR>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(GemmArgs p) {
-    constexpr bool DMA_IN_LOAD = (VAR & 1) != 0, DRAIN_LDS = (VAR & 2) != 0, PRIO = (VAR & 4) != 0;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = (VAR & 8) ? (wave & 1) : (wave >> 2);
-    const int wn = (VAR & 8) ? (wave >> 1) : (wave & 3);
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int gid = wg / per_group;
-        const int first_m = gid * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        const int in_g = wg - gid * per_group;
-        tm = first_m + in_g % gsz;
-        tn = in_g / gsz;
-    }
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    // staging: wave w streams A pieces 4w..4w+3 and W pieces 4w..4w+3 of every slab (1 KiB = 8 rows x 128 B each).
-    // Uniform 64-bit tile base (SGPR) + per-lane 32-bit element offsets keep the address state at 8 VGPRs.
-    const uint16_t* abase = p.A + (int64_t)m0 * p.lda;
-    const uint16_t* wbase = p.W + (int64_t)n0 * p.ldw;
-    int aoff[4], woff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        aoff[i] = min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8;
-        woff[i] = min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8;
-    }
-#define FW_STAGE_PIECE(S, KT, I)                                                                   \
-    do {                                                                                           \
-        FW_GLDS16(abase + (KT) * BK + aoff[I], smem + (S) * STAGE2 + (wave * 4 + (I)) * 1024);     \
-        FW_GLDS16(wbase + (KT) * BK + woff[I], smem + (S) * STAGE2 + TM * BK * 2 + (wave * 4 + (I)) * 1024); \
-    } while (0)
-#define FW_STAGE_FIRST(S, KT) do { FW_STAGE_PIECE(S, KT, 0); FW_STAGE_PIECE(S, KT, 1); } while (0)
-#define FW_STAGE_SECOND(S, KT) do { FW_STAGE_PIECE(S, KT, 2); FW_STAGE_PIECE(S, KT, 3); } while (0)
-
-    const int fi = lane & 31, hi = lane >> 5;
-    const int swz = (fi >> 1) & 7;
-    int coff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + hi) ^ swz) << 4;
-    const int a_row_off = (grp * 128 + fi) * 128;                    // + rb*32*128, rb = 0..3
-    const int b_row_off = TM * BK * 2 + (wn * 64 + fi) * 128;        // + nb*32*128
-
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8_t afr[2][4], bfr[2][4];
-
-    const int nk = p.K / BK;
-    FW_STAGE_FIRST(0, 0);
-    FW_STAGE_SECOND(0, 0);
-    FW_WAIT_DMA();
-    FW_BARRIER();
-    if (grp == 1) FW_BARRIER();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* base = smem + (kt & 1) * STAGE2;
-        const bool more = kt + 1 < nk;
-        const int ns = (kt + 1) & 1;
-        // ---------------- phase (kt, 0): B fragments + A rows 0..63 of the wave tile.
-        // DMA of slab kt+1 is issued only from LOAD segments (never in front of an MFMA burst): group A issues half in
-        // each of its two LOAD segments (slots 4t, 4t+2), group B all of it in LOAD(kt,0) (slot 4t+1).  Every LOAD
-        // segment drains its own ds_reads (lgkmcnt(0)) BEFORE the barrier, so when a barrier releases, no read of the
-        // previous slab is in flight and the stage may be overwritten from slot 4t on.
-        if (more) {
-            if (DMA_IN_LOAD) {
-                FW_STAGE_FIRST(ns, kt + 1);
-                if (grp == 1) FW_STAGE_SECOND(ns, kt + 1);
-            } else if (grp == 1) {
-                FW_STAGE_FIRST(ns, kt + 1);
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bfr[0][ks] = *(const bf16x8_t*)(base + b_row_off + coff[ks]);
-            bfr[1][ks] = *(const bf16x8_t*)(base + b_row_off + 32 * 128 + coff[ks]);
-            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + coff[ks]);
-            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 32 * 128 + coff[ks]);
-        }
-        if (DRAIN_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        FW_BARRIER();
-        if (!DMA_IN_LOAD && more) {
-            if (grp == 0) FW_STAGE_FIRST(ns, kt + 1);
-            else FW_STAGE_SECOND(ns, kt + 1);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[1][1], 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        FW_BARRIER();
-        // ---------------- phase (kt, 1): A rows 64..127 of the wave tile
-        if (grp == 0 && more) FW_STAGE_SECOND(ns, kt + 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + 64 * 128 + coff[ks]);
-            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 96 * 128 + coff[ks]);
-        }
-        if (DRAIN_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 1) FW_WAIT_DMA();          // group B: end of slot 4t+3
-        FW_BARRIER();
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[2][0], 0, 0, 0);
-            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[2][1], 0, 0, 0);
-            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[3][0], 0, 0, 0);
-            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[3][1], 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) FW_WAIT_DMA();          // group A: end of slot 4t+3
-        FW_BARRIER();
-    }
-    if (grp == 0) FW_BARRIER();
-
-    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// 256x256 tile, k streamed in HALF-SLABS of 32 through a 5-deep LDS ring (5 x 32 KiB = all 160 KiB of the CU).
-//
-// Why: with two 64 KiB stages a slab's DMA has at most ~1 slab time to land and every slab ends in vmcnt(0); a
-// global_load_lds that misses L2 needs ~1-2.5k cycles under load, so the matrix pipe idles on the slowest piece of every
-// slab.  Here a half-slab is requested FOUR half-slabs (8 barrier slots) before its first read and retired with a COUNTED
-// vmcnt (12 / 8 pieces still in flight), so the loop never drains the DMA queue.
-//
-// 8 waves = 2 (M) x 4 (N), wave tile 128 x 64 = 8 accumulators of 32x32 (v_mfma_f32_32x32x16_bf16); per half-slab a wave
-// does 12 ds_read_b128 (A 4x2, B 2x2) and 16 MFMA.  The two 4-wave groups (waves sharing a SIMD are in different groups)
-// run one barrier slot apart, so one is in its MFMA burst while its SIMD partner reads LDS:
-//     slot:        2h          2h+1        2h+2
-//     group A:   LOAD(h)     MFMA(h)     LOAD(h+1)
-//     group B:   MFMA(h-1)   LOAD(h)     MFMA(h)
-// Ring slot h%5 is last read in slot 2h+1 (reads drained with lgkmcnt(0) before the barrier), and rewritten with half-slab
-// h+5-1 = h+4's successor: every wave issues its 4 pieces of half-slab h+4 from INSIDE MFMA(h) (slot >= 2h+1 > 2(h-1)+1),
-// interleaved with the MFMAs so the issue cost hides behind the matrix pipe.  Half-slab j must be complete before group A's
-// LOAD(j) in slot 2j: group A waits vmcnt(12) at the end of MFMA(j-1) (younger: j+1..j+3), group B waits vmcnt(8) at the end
-// of LOAD(j-1) (younger: j+1, j+2); both waits precede the barrier that ends slot 2j-1.
-// LDS image of a half-slab: 512 rows (256 A, 256 W) x 64 B, 16-B chunk index XOR ((row>>2)&3) -- applied to the per-lane
-// SOURCE address of the DMA (destination is lane-linear) and again on the read: conflict-free ds_read_b128.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int HK = 32;                          // k per half-slab
-constexpr int RING = 5;
-constexpr int HSLAB = (TM + TN) * HK * 2;       // 32 KiB
-
 template <int N> __device__ __forceinline__ void fw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int VAR>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(GemmArgs p) {
-    constexpr bool PRIO = (VAR & 1) != 0;        // s_setprio(1) around the MFMA burst
-    constexpr bool DMA_HEAD = (VAR & 2) != 0;    // issue the 4 DMA pieces in front of the burst instead of inside it
-    constexpr bool NO_DMA = (VAR & 4) != 0;      // ablation: never restage (wrong results; measures the LDS/MFMA/barrier loop)
-    constexpr bool DMA_LOAD = (VAR & 8) != 0;    // issue the 4 DMA pieces from the LOAD slot (while the SIMD partner owns the matrix pipe)
-    constexpr bool ROW128 = (VAR & 64) != 0;     // ablation (wrong results): every DMA instruction reads 8 rows x 128 B instead of 16 rows x 64 B
-    constexpr bool FEW_LANES = (VAR & 32) != 0;  // ablation (wrong results): only 4 lanes of every DMA instruction active (same instruction count, 1/16 of the bytes)
-    constexpr bool SAME_ADDR = (VAR & 16) != 0;  // ablation (wrong results): every DMA re-reads half-slab 0 (L2-hot) -- memory system vs CU-internal cost
-    __shared__ __attribute__((aligned(16))) char smem[RING * HSLAB];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int wn = wave & 3;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int gid = wg / per_group;
-        const int first_m = gid * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        const int in_g = wg - gid * per_group;
-        tm = first_m + in_g % gsz;
-        tn = in_g / gsz;
-    }
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    // ---- DMA addressing: wave w streams A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of every half-slab (1 KiB = 16 rows x 64 B).
-    // Uniform 64-bit base (SGPR pair, advanced by 64 B per half-slab) + per-lane unsigned 32-bit byte offset (VGPR): the
-    // saddr form of global_load_lds, no per-piece 64-bit VALU address arithmetic.
-    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
-    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
-    unsigned aoff[2], woff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int row = (wave * 2 + i) * 16 + (lane >> 2);
-        int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        if (ROW128) { row = (wave * 2 + i) * 16 + (lane >> 3); chunk = lane & 7; }
-        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
-        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
-    }
-#define FW_RING_PIECE_A(RS, H, I) if (!FEW_LANES || lane < 4) FW_GLDS16(abase + (size_t)(SAME_ADDR ? 0 : (H)) * (HK * 2) + aoff[I], smem + (RS) * HSLAB + (wave * 2 + (I)) * 1024)
-#define FW_RING_PIECE_W(RS, H, I) if (!FEW_LANES || lane < 4) FW_GLDS16(wbase + (size_t)(SAME_ADDR ? 0 : (H)) * (HK * 2) + woff[I], smem + (RS) * HSLAB + TM * HK * 2 + (wave * 2 + (I)) * 1024)
-
-    // ---- fragment read offsets: row R, logical chunk c = 2*ks + hi, physical chunk = c ^ ((R>>2)&3) ---------------------
-    const int fi = lane & 31, hi = lane >> 5;
-    const int f = (fi >> 2) & 3;
-    const int a_off0 = (grp * 128 + fi) * 64 + (((0 + hi) ^ f) << 4);
-    const int a_off1 = (grp * 128 + fi) * 64 + (((2 + hi) ^ f) << 4);
-    const int b_off0 = TM * HK * 2 + (wn * 64 + fi) * 64 + (((0 + hi) ^ f) << 4);
-    const int b_off1 = TM * HK * 2 + (wn * 64 + fi) * 64 + (((2 + hi) ^ f) << 4);
-
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8_t afr[4][2], bfr[2][2];
-
-    const int nh = p.K / HK;        // >= 8 (launcher)
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        FW_RING_PIECE_A(h, h, 0); FW_RING_PIECE_W(h, h, 0); FW_RING_PIECE_A(h, h, 1); FW_RING_PIECE_W(h, h, 1);
-    }
-    fw_wait_vm<12>();
-    FW_BARRIER();
-    if (grp == 1) FW_BARRIER();
-
-    int rs = 0;                      // ring slot of half-slab h
-    int h = 0;
-    // one LOAD(h) | barrier | MFMA(h) (+ DMA of half-slab h+4 when MORE) | barrier
-    auto iter = [&](auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value && !NO_DMA;
-        // ------------------------------------------------ LOAD(h)
-        {
-            const char* base = smem + rs * HSLAB;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                bfr[nb][0] = *(const bf16x8_t*)(base + b_off0 + nb * 2048);
-                bfr[nb][1] = *(const bf16x8_t*)(base + b_off1 + nb * 2048);
-            }
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                afr[rb][0] = *(const bf16x8_t*)(base + a_off0 + rb * 2048);
-                afr[rb][1] = *(const bf16x8_t*)(base + a_off1 + rb * 2048);
-            }
-        }
-        const int ns = rs == 0 ? 4 : rs - 1;
-        if (DMA_LOAD && MORE) {
-            // ring slot ns held half-slab h-1, last read in slot 2h-1 (group B's LOAD(h-1)); this LOAD runs in slot >= 2h
-            FW_RING_PIECE_A(ns, h + 4, 0); FW_RING_PIECE_W(ns, h + 4, 0); FW_RING_PIECE_A(ns, h + 4, 1); FW_RING_PIECE_W(ns, h + 4, 1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 1) {
-            if (!decltype(more_tag)::value) fw_wait_vm<0>();
-            else if (DMA_LOAD) fw_wait_vm<12>();      // younger than half-slab h+1: h+2, h+3, h+4
-            else fw_wait_vm<8>();                     // younger than half-slab h+1: h+2, h+3
-        }
-        FW_BARRIER();
-        // ------------------------------------------------ MFMA(h), DMA of half-slab h+4 into ring slot (rs+4)%5
-        if (DMA_HEAD && !DMA_LOAD && MORE) {
-            FW_RING_PIECE_A(ns, h + 4, 0); FW_RING_PIECE_W(ns, h + 4, 0); FW_RING_PIECE_A(ns, h + 4, 1); FW_RING_PIECE_W(ns, h + 4, 1);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[rb][ks], bfr[0][ks], acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[rb][ks], bfr[1][ks], acc[rb][1], 0, 0, 0);
-                if (!DMA_HEAD && !DMA_LOAD && MORE) {
-                    // one DMA piece after MFMAs 2, 6, 10, 14 of the burst
-                    if (ks == 0 && rb == 0) FW_RING_PIECE_A(ns, h + 4, 0);
-                    if (ks == 0 && rb == 2) FW_RING_PIECE_W(ns, h + 4, 0);
-                    if (ks == 1 && rb == 0) FW_RING_PIECE_A(ns, h + 4, 1);
-                    if (ks == 1 && rb == 2) FW_RING_PIECE_W(ns, h + 4, 1);
-                }
-            }
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) { if (decltype(more_tag)::value) fw_wait_vm<12>(); else fw_wait_vm<0>(); }
-        FW_BARRIER();
-        rs = rs == RING - 1 ? 0 : rs + 1;
-    };
-    for (; h < nh - 4; ++h) iter(std::true_type{});
-    for (; h < nh; ++h) iter(std::false_type{});
-    if (grp == 0) FW_BARRIER();
-    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// 256x256 tile with FOUR waves (256 threads), one wave per SIMD owning the whole register file: wave tile 128 x 128 =
-// 16 accumulators of 32x32 (256 accumulator registers, placed in the AGPR half by the compiler) + fragments / addresses
-// in the 256 architectural VGPRs.  No inter-wave ping-pong: every wave software-pipelines ITS OWN stream -- fragment
-// ds_reads of the next k-step and the LDS-DMA of a later half-slab are issued between the MFMAs of the current k-step
-// (32 MFMAs per 32-wide half-slab, one ds_read_b128 per 2 MFMAs, one DMA piece per 4), so the matrix pipe is fed by a
-// single in-order instruction stream and there is only ONE barrier per half-slab (DMA visibility + ring reuse).
-// LDS traffic per slab drops to 2/3 of the 8-wave kernels (wave tile 128x128 instead of 128x64).
-// Ring: the same 5 x 32 KiB half-slab ring and swizzle as gemm_bf16_ring_kernel.  In iteration h (compute half-slab h) the
-// wave issues its 8 pieces of half-slab h+4 into the slot of half-slab h-1 (all reads of h-1 retired before the barrier
-// of iteration h-1) and, before the barrier that opens half-slab h+1, waits vmcnt(20): younger than its pieces of h+1 are
-// h+2, h+3 (16) and the first 4 pieces of h+4.
-// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of the four-wave kernel (wave tile 128 x 128): four 32-row passes through a private 16 KiB LDS region.
 __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x16_t (&acc)[4][4], int wave, int wm, int wn,
                                             int fi, int hi, int lane, int m0, int n0) {
     // Pass rb: the wave's 32 x 128 fp32 block goes through a private 16 KiB LDS region (raw accumulators in, row-contiguous
@@ -646,142 +309,13 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
     }
 }
 
-template <int VAR>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
-    constexpr bool PRIO = (VAR & 1) != 0;
-    constexpr bool NO_DMA = (VAR & 4) != 0;      // ablation (wrong results)
-    __shared__ __attribute__((aligned(16))) char smem[RING * HSLAB];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int gid = wg / per_group;
-        const int first_m = gid * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        const int in_g = wg - gid * per_group;
-        tm = first_m + in_g % gsz;
-        tn = in_g / gsz;
-    }
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    // DMA: wave w streams A pieces 4w..4w+3 and W pieces 4w..4w+3 of every half-slab (1 KiB = 16 rows x 64 B)
-    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
-    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
-    unsigned aoff[4], woff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
-        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
-    }
-#define FW_W4_PIECE_A(RS, H, I) FW_GLDS16(abase + (size_t)(H) * (HK * 2) + aoff[I], smem + (RS) * HSLAB + (wave * 4 + (I)) * 1024)
-#define FW_W4_PIECE_W(RS, H, I) FW_GLDS16(wbase + (size_t)(H) * (HK * 2) + woff[I], smem + (RS) * HSLAB + TM * HK * 2 + (wave * 4 + (I)) * 1024)
-
-    const int fi = lane & 31, hi = lane >> 5;
-    const int f = (fi >> 2) & 3;
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        a_off[ks] = (wm * 128 + fi) * 64 + (((2 * ks + hi) ^ f) << 4);
-        b_off[ks] = TM * HK * 2 + (wn * 128 + fi) * 64 + (((2 * ks + hi) ^ f) << 4);
-    }
-
-    f32x16_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8_t a0[4], b0[4], a1[4], b1[4];         // fragment sets of k-step 0 / 1 of a half-slab
-
-    const int nh = p.K / HK;        // >= 8 (launcher)
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { FW_W4_PIECE_A(h, h, i); FW_W4_PIECE_W(h, h, i); }
-    }
-    fw_wait_vm<24>();
-    FW_BARRIER();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a0[i] = *(const bf16x8_t*)(smem + a_off[0] + i * 2048);
-        b0[i] = *(const bf16x8_t*)(smem + b_off[0] + i * 2048);
-    }
-
-    int rs = 0;
-    int h = 0;
-    auto iter = [&](auto more_tag, auto last_tag) {
-        constexpr bool MORE = decltype(more_tag)::value && !NO_DMA;     // half-slab h+4 exists
-        constexpr bool LAST = decltype(last_tag)::value;                // h == nh-1
-        const char* base = smem + rs * HSLAB;
-        const int ns = rs == 0 ? 4 : rs - 1;       // ring slot of half-slab h+4 (== h-1)
-        const int nx = rs == RING - 1 ? 0 : rs + 1;
-        // ---- k-step 0: prefetch k-step 1 fragments, first half of the DMA, 16 MFMAs on set 0
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a1[i] = *(const bf16x8_t*)(base + a_off[1] + i * 2048);
-            b1[i] = *(const bf16x8_t*)(base + b_off[1] + i * 2048);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[rb], b0[nb], acc[rb][nb], 0, 0, 0);
-            if (MORE) { if (rb & 1) FW_W4_PIECE_W(ns, h + 4, rb >> 1); else FW_W4_PIECE_A(ns, h + 4, rb >> 1); }
-        }
-        // ---- k-step 1: open half-slab h+1 (own pieces landed -> barrier), prefetch its k-step 0, rest of the DMA, 16 MFMAs
-        if (!LAST) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (MORE) fw_wait_vm<20>(); else fw_wait_vm<0>();
-            FW_BARRIER();
-            const char* nbase = smem + nx * HSLAB;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a0[i] = *(const bf16x8_t*)(nbase + a_off[0] + i * 2048);
-                b0[i] = *(const bf16x8_t*)(nbase + b_off[0] + i * 2048);
-            }
-        }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rb], b1[nb], acc[rb][nb], 0, 0, 0);
-            if (MORE) { if (rb & 1) FW_W4_PIECE_W(ns, h + 4, 2 + (rb >> 1)); else FW_W4_PIECE_A(ns, h + 4, 2 + (rb >> 1)); }
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        rs = nx;
-    };
-    for (; h < nh - 4; ++h) iter(std::true_type{}, std::false_type{});
-    for (; h < nh - 1; ++h) iter(std::false_type{}, std::false_type{});
-    iter(std::false_type{}, std::true_type{});
-    FW_BARRIER();
-    epilogue_w4(p, smem, acc, wave, wm, wn, fi, hi, lane, m0, n0);
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------
 // 256x256x64 ping-pong kernel, 128-B LDS rows, two 64 KiB stages, quarter-slab DMA scheduling with counted waits.
 //
 // Measured on MI355X (tools/probes/dma_probe.hip): the LDS-DMA ingest of a CU tops out at ~107 GB/s with 128-B global
 // rows but only ~67 GB/s with 64-B rows (57 vs 85 GB/s beside ds_read traffic), and the GEMM's cost scales with the BYTES
-// it streams, not with the number of DMA instructions.  So this kernel keeps full 128-B rows (k-slab 64) like
-// gemm_bf16_256_kernel, and gets its prefetch distance from scheduling instead of from more LDS: a slab is four 16 KiB
+// it streams, not with the number of DMA instructions.  So this kernel keeps full 128-B rows (k-slab 64)
+// and gets its prefetch distance from scheduling instead of from more LDS: a slab is four 16 KiB
 // units -- A0 = tile rows 0..127 (read only by wave group A), A1 = rows 128..255 (group B), B0/B1 = the W rows -- and a
 // unit of slab t+2 is requested as soon as the same unit of slab t has been read for the last time:
 //     slot:        4t        4t+1      4t+2      4t+3      4t+4
@@ -794,137 +328,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(GemmArgs p) {
 //     group B: end of LOAD1(t): vmcnt(2) -> own B/A0(t+1) landed;   end of MFMA1(t): vmcnt(6) -> own A1(t+1) landed
 //   each ahead of the barrier that precedes the first read of that unit by any wave.
 // ---------------------------------------------------------------------------------------------------------------
-template <int VAR>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
-    constexpr bool PRIO = (VAR & 1) != 0;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int wn = wave & 3;
-
-    const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, slot = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int gid = wg / per_group;
-        const int first_m = gid * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        const int in_g = wg - gid * per_group;
-        tm = first_m + in_g % gsz;
-        tn = in_g / gsz;
-    }
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    // DMA pieces (1 KiB = 8 rows x 128 B).  Wave w owns, in every 128-row unit, pieces 2w and 2w+1 (rows 16w .. 16w+15).
-    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
-    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
-    unsigned aoff[2][2], woff[2][2];       // [unit][piece]
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = u * 128 + (wave * 2 + i) * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            aoff[u][i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
-            woff[u][i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
-        }
 #define FW_PP_A(S, KT, U, I) FW_GLDS16(abase + (size_t)(KT) * (BK * 2) + aoff[U][I], smem + (S) * STAGE2 + ((U) * 16 + wave * 2 + (I)) * 1024)
 #define FW_PP_W(S, KT, U, I) FW_GLDS16(wbase + (size_t)(KT) * (BK * 2) + woff[U][I], smem + (S) * STAGE2 + TM * BK * 2 + ((U) * 16 + wave * 2 + (I)) * 1024)
 #define FW_PP_ISSUE6(S, KT) do { FW_PP_W(S, KT, 0, 0); FW_PP_W(S, KT, 0, 1); FW_PP_W(S, KT, 1, 0); FW_PP_W(S, KT, 1, 1); FW_PP_A(S, KT, 0, 0); FW_PP_A(S, KT, 0, 1); } while (0)
 #define FW_PP_ISSUE2(S, KT) do { FW_PP_A(S, KT, 1, 0); FW_PP_A(S, KT, 1, 1); } while (0)
 
-    const int fi = lane & 31, hi = lane >> 5;
-    const int swz = (fi >> 1) & 7;
-    int coff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) coff[ks] = ((2 * ks + hi) ^ swz) << 4;
-    const int a_row_off = (grp * 128 + fi) * 128;                    // + rb*32*128, rb = 0..3
-    const int b_row_off = TM * BK * 2 + (wn * 64 + fi) * 128;        // + nb*32*128
-
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8_t afr[2][4], bfr[2][4];
-
-    const int nk = p.K / BK;       // >= 4 (launcher)
-    FW_PP_ISSUE6(0, 0); FW_PP_ISSUE2(0, 0);
-    FW_PP_ISSUE6(1, 1); FW_PP_ISSUE2(1, 1);
-    fw_wait_vm<8>();
-    FW_BARRIER();
-    if (grp == 1) FW_BARRIER();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* base = smem + (kt & 1) * STAGE2;
-        const int st = kt & 1;
-        const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
-        // ---------------- LOAD0(kt): B fragments + A rows 0..63 of the wave tile
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bfr[0][ks] = *(const bf16x8_t*)(base + b_row_off + coff[ks]);
-            bfr[1][ks] = *(const bf16x8_t*)(base + b_row_off + 32 * 128 + coff[ks]);
-            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + coff[ks]);
-            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 32 * 128 + coff[ks]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 0) { if (has1) fw_wait_vm<6>(); else fw_wait_vm<0>(); }
-        FW_BARRIER();
-        // ---------------- MFMA0(kt) (+ A1 unit of slab kt+1 into the other stage; slabs 0 and 1 come from the prologue)
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[0][1], 0, 0, 0);
-            if (ks == 0 && kt >= 1 && has1) FW_PP_ISSUE2(st ^ 1, kt + 1);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[1][1], 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        FW_BARRIER();
-        // ---------------- LOAD1(kt): A rows 64..127 of the wave tile
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            afr[0][ks] = *(const bf16x8_t*)(base + a_row_off + 64 * 128 + coff[ks]);
-            afr[1][ks] = *(const bf16x8_t*)(base + a_row_off + 96 * 128 + coff[ks]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (grp == 1) { if (has1) fw_wait_vm<2>(); else fw_wait_vm<0>(); }
-        FW_BARRIER();
-        // ---------------- MFMA1(kt) (+ B and A0 units of slab kt+2 into this stage)
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[2][0], 0, 0, 0);
-            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[2][1], 0, 0, 0);
-            if (ks == 0 && has2) FW_PP_ISSUE6(st, kt + 2);
-            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[3][0], 0, 0, 0);
-            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[3][1], 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) { if (has2) fw_wait_vm<8>(); else if (has1) fw_wait_vm<2>(); else fw_wait_vm<0>(); }
-        else { if (has2) fw_wait_vm<6>(); else fw_wait_vm<0>(); }
-        FW_BARRIER();
-    }
-    if (grp == 0) FW_BARRIER();
-    epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Second generation of the ping-pong kernel (round 2, the default).  Same tile, LDS image, slot table, DMA placement, counted waits
-// and fragment reads as gemm_bf16_pp_kernel; what changed was read off the ISA:
+// Round 2 (against round 1's gemm_bf16_pp_kernel, same slot table): what changed was read off the ISA:
 //   * the loop is peeled by hand (first / steady / second-last / last slab as compile-time flags), so a phase is ONE basic block;
 //   * the accumulators are pinned by an empty asm after every burst, so no MFMA drifts across the barrier that follows.
 // +2..5 % on the DiT shapes (profiles/r02/gemm_experiments.md).  Tried on this skeleton and measured WITHOUT gain, hence not kept:
@@ -1084,6 +494,179 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256x64 tile with FOUR waves, one per SIMD with the whole 512-entry register file (wave tile 128 x 128 = 16 accumulators in
+// the accumulation half), 128-B LDS rows in two 64 KiB stages -- the shape of the vendor library's kernel for these GEMMs
+// (rocprofv3 on torch.matmul: a hand-written MT256x256x64 kernel, 256 threads, 130 KiB LDS, 1.43-1.58 PF on this box).  Against
+// gemm_bf16_w4_kernel (half-slab ring, compiler-ordered): full 128-B rows for the LDS-DMA, ONE barrier per 64 MFMAs, and an
+// instruction order pinned by hand with sched_barrier: per k-step 16 MFMAs with the 8 fragment reads of the NEXT k-step and the
+// LDS-DMA pieces dealt out between them, so no wait ever covers reads that were issued just before it.
+//   after the barrier of slab T (slab T+1 landed, every wave done reading slab T):
+//     P3: MFMA k-step 3 of slab T   | read frags(T+1, k0) | DMA 8 pieces of slab T+2 -> stage of T
+//     P0: MFMA k-step 0 of slab T+1 | read frags(T+1, k1) | DMA the other 8 pieces
+//     P1: MFMA k-step 1             | read frags(T+1, k2)
+//     P2: MFMA k-step 2             | read frags(T+1, k3) ; lgkmcnt(0), vmcnt(0), s_barrier
+// Per wave and slab: 64 MFMAs (2048 cycles), 32 ds_read_b128, 16 DMA pieces; LDS reads per slab and CU 128 KiB (8-wave kernels: 192).
+// ---------------------------------------------------------------------------------------------------------------
+#define FW_NOMOVE() __builtin_amdgcn_sched_barrier(0)
+
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4b_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // DMA pieces (1 KiB = 8 rows x 128 B): wave w streams A pieces 8w..8w+7 (tile rows 64w .. 64w+63) and the same W pieces.
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[8], woff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+    }
+#define FW_4B_A(S, KT, I) FW_GLDS16(abase + (size_t)(KT) * (BK * 2) + aoff[I], smem + (S) * STAGE2 + (wave * 8 + (I)) * 1024)
+#define FW_4B_W(S, KT, I) FW_GLDS16(wbase + (size_t)(KT) * (BK * 2) + woff[I], smem + (S) * STAGE2 + TM * BK * 2 + (wave * 8 + (I)) * 1024)
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int a_addr[4], b_addr[4];              // byte offsets of this lane's fragment chunk of k-step ks in stage 0 (+ rb * 4096)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = ((2 * ks + hi) ^ swz) << 4;
+        a_addr[ks] = (wm * 128 + fi) * 128 + c;
+        b_addr[ks] = TM * BK * 2 + (wn * 128 + fi) * 128 + c;
+    }
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t fa[2][4], fb[2][4];           // [set][row / column block]
+
+    const int nk = p.K / BK;               // >= 4 (launcher)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { FW_GLDS16(abase + aoff[i], smem + (wave * 8 + i) * 1024); FW_GLDS16(wbase + woff[i], smem + TM * BK * 2 + (wave * 8 + i) * 1024); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { FW_GLDS16(abase + BK * 2 + aoff[i], smem + STAGE2 + (wave * 8 + i) * 1024); FW_GLDS16(wbase + BK * 2 + woff[i], smem + STAGE2 + TM * BK * 2 + (wave * 8 + i) * 1024); }
+    fw_wait_vm<16>();
+    FW_BARRIER();
+
+    // One k-step: 16 MFMAs on fragment set CUR, with (READ) the 8 fragment reads of k-step `rks` of stage `rst` into the other set
+    // after MFMAs 0..7 and (NDMA pieces, first one = piece `p0`) LDS-DMA pieces of slab `dk` into stage `dst` dealt out between
+    // the MFMAs; nothing may be reordered.  A global_load_lds_dwordx4 occupies the CU's one texture-address path for 16 cycles
+    // (1 KiB at 64 B/clk) and BLOCKS the issuing wave until it is accepted: four waves issuing their pieces together serialise
+    // behind each other (~60 cycles each, matrix pipe idle -- measured: +1000 cycles per slab, exactly 64 pieces x 16 cycles).  So
+    // the pieces are spread over three k-steps (one per 3 MFMAs) and the waves take DIFFERENT MFMA slots (slot = 3 i + wave % 3)
+    // -- which, measured, changes nothing either way (1100 TF/s spread or bunched): the cost follows the BYTES, see DESIGN.md.
+    const int dslot = wave % 3;
+    auto kstep = [&](auto cur_tag, auto read_tag, auto dma_tag, int rst, int rks, int dst, int dk) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr bool READ = decltype(read_tag)::value;
+        constexpr int GB = decltype(dma_tag)::value;            // -1: no DMA in this k-step; else first of its 16 global MFMA slots (0 / 16 / 32)
+        const char* rbase = smem + rst * STAGE2;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[CUR][rb], fb[CUR][nb], acc[rb][nb], 0, 0, 0);
+                const int j = rb * 4 + nb;                      // 0..15
+                if (READ && j < 8) {                            // a0 b0 a1 b1 .. : the last read is 8 MFMAs old at the next k-step
+                    FW_NOMOVE();
+                    if (j & 1) fb[CUR ^ 1][j >> 1] = *(const bf16x8_t*)(rbase + b_addr[rks] + (j >> 1) * 4096);
+                    else fa[CUR ^ 1][j >> 1] = *(const bf16x8_t*)(rbase + a_addr[rks] + (j >> 1) * 4096);
+                    FW_NOMOVE();
+                }
+                if (GB >= 0) {                                  // the 48 MFMA slots of P3, P0, P1 carry the 16 pieces: piece g / 3 in the
+                    const int g = GB + j;                       // wave's own slot (g % 3 == dslot) of every MFMA triple
+                    FW_NOMOVE();
+                    if (g % 3 == dslot) {
+                        const int i = g / 3;                    // 0..15: A pieces 0..7, then W pieces 0..7
+                        if (i < 8) { FW_4B_A(dst, dk, i); } else { FW_4B_W(dst, dk, i - 8); }
+                    }
+                    FW_NOMOVE();
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using DN = std::integral_constant<int, -1>;
+    using D0 = std::integral_constant<int, 0>;
+    using D16 = std::integral_constant<int, 16>;
+    using D32 = std::integral_constant<int, 32>;
+
+    // prologue: slab 0 k-steps 0..2 (no DMA: stage 0 is still being read), then the barrier that opens slab 1
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        fa[0][rb] = *(const bf16x8_t*)(smem + a_addr[0] + rb * 4096);
+        fb[0][rb] = *(const bf16x8_t*)(smem + b_addr[0] + rb * 4096);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    kstep(S0{}, T{}, DN{}, 0, 1, 0, 0);
+    kstep(S1{}, T{}, DN{}, 0, 2, 0, 0);
+    kstep(S0{}, T{}, DN{}, 0, 3, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fw_wait_vm<0>();
+    FW_BARRIER();
+
+    // steady state: T = slab whose k-step 3 is pending in set 1; slab T+1 landed in stage (T+1)&1; slab T+2 goes to stage T&1
+    int Tk = 0;
+    auto body = [&](auto has2_tag) {
+        constexpr bool HAS2 = decltype(has2_tag)::value;
+        const int sn = (Tk + 1) & 1, so = Tk & 1;
+        if (HAS2) {
+            kstep(S1{}, T{}, D0{}, sn, 0, so, Tk + 2);          // P3: MFMA slots  0..15
+            kstep(S0{}, T{}, D16{}, sn, 1, so, Tk + 2);         // P0: MFMA slots 16..31
+            kstep(S1{}, T{}, D32{}, sn, 2, so, Tk + 2);         // P1: MFMA slots 32..47
+        } else {
+            kstep(S1{}, T{}, DN{}, sn, 0, so, 0);
+            kstep(S0{}, T{}, DN{}, sn, 1, so, 0);
+            kstep(S1{}, T{}, DN{}, sn, 2, so, 0);
+        }
+        kstep(S0{}, T{}, DN{}, sn, 3, so, 0);                   // P2: a k-step without DMA lets the last pieces land
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fw_wait_vm<0>();
+        FW_BARRIER();
+        ++Tk;
+    };
+    while (Tk < nk - 2) body(T{});
+    body(F{});                                                  // Tk = nk-2: slab nk-1 k-steps 0..2, no more DMA
+    kstep(S1{}, F{}, DN{}, 0, 0, 0, 0);                         // k-step 3 of the last slab
+    __builtin_amdgcn_s_setprio(0);
+    FW_BARRIER();
+    epilogue_w4(p, smem, acc, wave, wm, wn, fi, hi, lane, m0, n0);
+}
+
 // fp32 GEMV for the M=1 time-embedding MLPs: one wave per output feature.
 __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, float* __restrict__ out,
@@ -1134,14 +717,15 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     const uintptr_t rmask = (res_dtype == FW_DT_F32) ? 15 : 7;
     if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & cmask) || (res && ((ldr % 4) || (((uintptr_t)res) & rmask)))) big = false;
     if ((((uintptr_t)bias) | ((uintptr_t)g1) | ((uintptr_t)g0)) & 15) big = false;   // per-column vectors are read 16 B at a time
-    if (big) {
+    if (big && K >= 4 * BK) {
+        // FW_GEMM_KERNEL: 4 (default) = ping-pong kernel, with the four-wave kernel for short K; 5 = four-wave kernel everywhere
         const int kern = fw_get_option(FW_OPT_GEMM_KERNEL);
         // Short M tail (VGGT: 32865 rows = 128 full row bands + 97 rows): a 129th band of 256-row tiles costs a whole extra
         // round of the grid (516 tiles on 256 CUs = 3 rounds for 2.02 rounds of work).  Peel it: the full bands go to the 256x256
         // kernel (512 tiles = 2 rounds), the <= 128 leftover rows to the 128x128 kernel in a second, tiny launch.  Same
         // k-order per output element in both kernels, disjoint output rows.
         const int tail = M % TM;
-        if ((kern == 3 || kern == 4) && tail > 0 && tail <= BM && M >= 2 * TM) {
+        if (tail > 0 && tail <= BM && M >= 2 * TM) {
             const int Mfull = M - tail;
             const size_t cbytes = (out_dtype == FW_DT_F32) ? 4 : 2, rbytes = (res_dtype == FW_DT_F32) ? 4 : 2;
             int rc = fw_gemm_bf16(A, lda, W, ldw, C, ldc, out_dtype, Mfull, N, K, bias, act, g1, g0, res, ldr, res_dtype, stream);
@@ -1158,53 +742,15 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
-        const int var = fw_get_option(FW_OPT_GEMM_VAR);
         hipStream_t st = (hipStream_t)stream;
-        if (kern == 4 && K >= 4 * BK) {
-            if (var & 2) hipLaunchKernelGGL(gemm_bf16_pp2_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
-            else hipLaunchKernelGGL(gemm_bf16_pp2_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, st, p);
-            return (int)hipGetLastError();
-        }
-        if (kern == 3 && K >= 4 * BK) {
-            if (var == 1) hipLaunchKernelGGL(gemm_bf16_pp_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p);
-            else hipLaunchKernelGGL(gemm_bf16_pp_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p);
-            return (int)hipGetLastError();
-        }
-        if (kern == 2 && K >= 8 * HK) {
-            switch (var) {
-                case 1: hipLaunchKernelGGL(gemm_bf16_w4_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, p); break;
-                case 4: hipLaunchKernelGGL(gemm_bf16_w4_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, p); break;
-                default: hipLaunchKernelGGL(gemm_bf16_w4_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, p); break;
-            }
-            return (int)hipGetLastError();
-        }
-        if (kern == 1 && K >= 8 * HK) {
-            switch (var) {
-                case 1: hipLaunchKernelGGL(gemm_bf16_ring_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 2: hipLaunchKernelGGL(gemm_bf16_ring_kernel<2>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 3: hipLaunchKernelGGL(gemm_bf16_ring_kernel<3>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 4: hipLaunchKernelGGL(gemm_bf16_ring_kernel<4>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 5: hipLaunchKernelGGL(gemm_bf16_ring_kernel<5>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 8: hipLaunchKernelGGL(gemm_bf16_ring_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 9: hipLaunchKernelGGL(gemm_bf16_ring_kernel<9>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 16: hipLaunchKernelGGL(gemm_bf16_ring_kernel<16>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 32: hipLaunchKernelGGL(gemm_bf16_ring_kernel<32>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 48: hipLaunchKernelGGL(gemm_bf16_ring_kernel<48>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                case 64: hipLaunchKernelGGL(gemm_bf16_ring_kernel<64>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-                default: hipLaunchKernelGGL(gemm_bf16_ring_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            }
-            return (int)hipGetLastError();
-        }
-        switch (var) {
-            case 1: hipLaunchKernelGGL(gemm_bf16_256_kernel<1>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 2: hipLaunchKernelGGL(gemm_bf16_256_kernel<2>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 3: hipLaunchKernelGGL(gemm_bf16_256_kernel<3>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 4: hipLaunchKernelGGL(gemm_bf16_256_kernel<4>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 6: hipLaunchKernelGGL(gemm_bf16_256_kernel<6>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 7: hipLaunchKernelGGL(gemm_bf16_256_kernel<7>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 8: hipLaunchKernelGGL(gemm_bf16_256_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            case 12: hipLaunchKernelGGL(gemm_bf16_256_kernel<12>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
-            default: hipLaunchKernelGGL(gemm_bf16_256_kernel<0>, dim3((unsigned)nwg), dim3(512), 0, st, p); break;
+        // short K: prologue and epilogue weigh more than the mainloop's schedule; the four-wave kernel measures +8..12 % there
+        // (VGGT qkv / fc1 at K = 1024, bicross output projections at K = 1152) and -6..-9 % from K = 4096 on
+        if (kern == 5 || (kern == 4 && K <= 1280)) {
+            hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
+            hipLaunchKernelGGL(gemm_bf16_pp2_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+        } else {
+            hipLaunchKernelGGL(gemm_bf16_pp2_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, st, p);
         }
         return (int)hipGetLastError();
     }

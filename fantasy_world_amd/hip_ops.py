@@ -20,7 +20,7 @@ ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
 
 # every symbol declared in include/fw_mi355x.h (tests check the library exports all of them)
 SYMBOLS = [
-    "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_v_transpose", "fw_layernorm_mod",
+    "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_attention_workspace_bytes", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
     "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_debug_gemm_timestamps", "fw_control_patchify", "fw_im2col3x3",
     "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
@@ -50,7 +50,7 @@ def load_library(path: str = LIB_PATH):
     lib.fw_last_error.argtypes = []
     sig = {
         "fw_gemm_bf16": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
-        "fw_attention_bf16": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, i32, vp],
+        "fw_attention_bf16": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, i32, vp, i64, vp],
         "fw_v_transpose": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_layernorm_mod": [vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp],
         "fw_qk_prep": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, f32, vp],
@@ -86,6 +86,8 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.restype = i32
         fn.argtypes = args
+    lib.fw_attention_workspace_bytes.restype = i64
+    lib.fw_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     if lib.fw_abi_version() != 7:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
@@ -144,6 +146,7 @@ class HipOps:
         if self.device.type != "cuda":
             raise RuntimeError("HipOps only runs on a HIP device")
         self._timing = None
+        self.split_kv = True           # split-KV for tail q-blocks that would cost an extra round (A/B: set False)
 
     # ---- live kernel timing (bench.py roofline): HIP events on the launch stream around selected launches -------------
     def start_kernel_timing(self, tags):
@@ -288,13 +291,19 @@ class HipOps:
         assert lk2 == Lk
         if out is None:
             out = torch.empty(batch * Lq, heads * hd, dtype=torch.bfloat16, device=self.device)
+        # scratch for the split-KV route of a tail q-block (PyTorch owns the memory; 0 bytes = the library would not use it)
+        ws, ws_bytes = None, 0
+        if q_prescaled and self.split_kv:
+            ws_bytes = int(self.lib.fw_attention_workspace_bytes(batch, heads, hd, Lq, Lk))
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         tok = None if self._timing is None else self._time_begin(
             dict(kind="attention", hd=hd, Lq=Lq, Lk=Lk, heads=heads, batch=batch))
         _check(self.lib.fw_attention_bf16(
             q.data_ptr(), q.stride(0), Lq * q.stride(0), k.data_ptr(), k.stride(0), Lk * k.stride(0),
             vt.data_ptr(), vt.shape[-1], out.data_ptr(), out.stride(0), Lq * out.stride(0),
             batch, heads, hd, Lq, Lk, 1.0 / math.sqrt(hd), (1 if accumulate else 0) | (2 if q_prescaled else 0),
-            self._stream()), "fw_attention_bf16")
+            _ptr(ws), ws_bytes, self._stream()), "fw_attention_bf16")
         self._time_end(tok)
         return out
 
@@ -490,14 +499,21 @@ class HipOps:
         return pts, conf
 
     # ---- fp8 linear (AutoWrappedLinear.fp8_linear, diffsynth_wan22/vram_management/layers.py:115-151) ----
-    def pack_linear_fp8(self, w, b):
-        """w [N, K] (K % 64 == 0) -> e4m3 bytes (raw cast, scale 1: layers.py:134,137); bias rounded to bf16 (layers.py:138)."""
+    def pack_linear_fp8(self, w, b, bias_through_fp8=True):
+        """w [N, K] (K % 64 == 0) -> e4m3 bytes (raw cast, scale 1: layers.py:134,137); bias rounded to bf16 (layers.py:138).
+        bias_through_fp8: AutoWrappedLinear.forward casts weight AND bias to the computation dtype before calling fp8_linear
+        (layers.py:158-159), so in the module the bias passes through e4m3 first; False = fp8_linear called directly."""
         assert w.shape[1] % 64 == 0, w.shape
         wb = w.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
         wq = torch.empty(wb.shape, dtype=torch.uint8, device=self.device)
         _check(self.lib.fw_fp8_quant_rows(wb.data_ptr(), wb.stride(0), wq.data_ptr(), wq.stride(0), None, wb.shape[0], wb.shape[1],
                                           1, self._stream()), "fw_fp8_quant_rows")
-        bb = None if b is None else b.detach().to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous()
+        bb = None
+        if b is not None:
+            bb = b.detach().to(device="cpu", dtype=torch.bfloat16)
+            if bias_through_fp8:
+                bb = bb.to(torch.float8_e4m3fn).to(torch.bfloat16)       # pack time, [N] values: on the host
+            bb = bb.to(device=self.device, dtype=torch.float32).contiguous()
         return Linear(wq, bb, fp8=True)
 
     def quantize_fp8_rows(self, x):

@@ -178,7 +178,9 @@ def install_flash_attention(modules, ops=None, device=None, name="flash_attentio
         lk = k.shape[1]
         hd = d // num_heads
         to2 = lambda t, n: ops.to_act(t.reshape(b * n, d))
-        out = ops.attention(to2(q, lq), to2(k, lk), to2(v, lk), num_heads, hd, batch=b)
+        # softmax_scale * log2(e) folded into a COPY of q (fw_qk_prep, one bf16 rounding): the log2-domain kernels take it from there
+        qs = ops.qk_prep(to2(q, lq).clone(), num_heads, hd, out_scale=ops.q_scale(hd))
+        out = ops.attention(qs, to2(k, lk), to2(v, lk), num_heads, hd, batch=b, q_prescaled=True)
         return out.view(b, lq, d).to(q.dtype)
 
     saved = [(m, getattr(m, name)) for m in modules]

@@ -60,16 +60,14 @@ int fw_abi_version(void);
  * Each slot is initialised once from the environment variable of the same name.
  */
 #define FW_OPT_GEMM_TILE   0   /* FW_GEMM_TILE: 0 = auto, 128 / 256 = force the tile family */
-#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 3 = 128-B-row ping-pong with quarter-slab DMA (default), 1 = 5-deep half-slab ring,
-                                  2 = four-wave 128x128 wave tile, 0 = first 2-stage staggered kernel (A/B baselines) */
-#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: schedule variant bits of the selected 256x256 kernel (default 1 = s_setprio around MFMA bursts) */
+#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 4 (default) = 8-wave ping-pong kernel, four-wave kernel for K <= 1280;
+                                  5 = four-wave 128x128-wave-tile kernel for every big GEMM (independent implementation, A/B) */
+#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: 0 (default); bit 1 = TIMING build of the ping-pong kernel (tools/gemm_timeline.py) */
 #define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
-                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): 129 for hd 128 / 64, 64 for hd 96;
-                                   calls without the flag use the 2-segment kernel.  64 = two-segment ping-pong kernels, +1 K/Q
-                                   fragments by LDS-DMA; 128 + bits = single-stream half-tile pipeline (bit 0 pinned issue order,
-                                   bit 1 one 64-row wave per SIMD), 160 + those bits = same with two tiles per barrier; 256 + bits = timing ablations of that kernel (wrong
-                                   results by construction, tools/microbench.py only); 32 + bits = 2-segment generic;
-                                   16 + bits = 4-segment ping-pong; 0 = the first kernel */
+                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): single-stream kernel (129) for hd
+                                   128 / 64, two-segment ping-pong (64) for hd 96.  131 = single-stream with one 64-row wave per
+                                   SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
+                                   WITHOUT the pre-scaled flag get) */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
 
@@ -112,6 +110,11 @@ int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
  *          FW_ATTN_Q_PRESCALED -> Q already carries the factor scale*log2(e) (fw_qk_prep out_scale): `scale` is ignored, the
  *          scores are used in the log2 domain as they come out of the MFMA (saves one multiply-add per score and lets the
  *          running max be folded into the accumulator input of QK^T) -- the fast ping-pong kernel needs this form.
+ *   workspace / workspace_bytes: optional caller-owned scratch (the library never allocates).  With at least
+ *          fw_attention_workspace_bytes(...) bytes and FW_ATTN_Q_PRESCALED, a tail q-block (Lq % 256 != 0) that would cost the
+ *          grid a whole extra round of the 256 CUs runs as split-KV instead (its keys cut into runs processed side by side,
+ *          un-normalised partial outputs merged by a second kernel); NULL / 0 = single launch.  Same result up to fp32
+ *          summation order.
  * fp32 online softmax, bf16 MFMA 32x32x16 for QK^T and PV.
  */
 #define FW_ATTN_ACCUMULATE  1
@@ -121,7 +124,9 @@ int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
                       const uint16_t* Vt, int64_t Lk_pad,
                       uint16_t* O, int64_t ldo, int64_t bso,
                       int batch, int heads, int head_dim, int Lq, int Lk,
-                      float scale, int flags, void* stream);
+                      float scale, int flags, void* workspace, int64_t workspace_bytes, void* stream);
+/* Scratch size with which fw_attention_bf16 takes the split-KV route for this shape; 0 = it would not use a workspace. */
+int64_t fw_attention_workspace_bytes(int batch, int heads, int head_dim, int Lq, int Lk);
 
 /*
  * V[batch][Lk][heads*hd] (ldv, bsv) -> Vt[batch][heads][hd][Lk_pad] in the key order fw_attention_bf16 expects.

@@ -106,6 +106,8 @@ def fp8_linear(x, weight, bias):
     scale_a = torch.clamp(x_max / 448.0, min=1.0).float()
     xq = (xb / (scale_a + 1e-8)).to(torch.float8_e4m3fn)
     wq = weight.to(torch.bfloat16).to(torch.float8_e4m3fn)
+    # AutoWrappedLinear.forward hands fp8_linear weight AND bias already cast to the computation dtype (layers.py:158-159)
+    bias = bias.to(torch.bfloat16).to(torch.float8_e4m3fn)
     y = (xq.float() @ wq.float().t()) * scale_a + bias.to(torch.bfloat16).float()
     return y.to(torch.bfloat16).float().reshape(*shape[:-1], -1)
 

@@ -314,9 +314,15 @@ class TorchRefOps:
         return self._r(self._act(x.to(torch.float32), act))
 
     # ---- fp8 linear ----------------------------------------------------------------------------------------
-    def pack_linear_fp8(self, w, b):
+    def pack_linear_fp8(self, w, b, bias_through_fp8=True):
         wq = self.to_f32(w).to(torch.bfloat16).to(torch.float8_e4m3fn)               # raw cast (layers.py:137)
-        return _Lin(wq, None if b is None else self.to_f32(b).to(torch.bfloat16).to(torch.float32), fp8=True)
+        bb = None
+        if b is not None:
+            bb = self.to_f32(b).to(torch.bfloat16)
+            if bias_through_fp8:          # AutoWrappedLinear.forward: cast_to(bias, computation_dtype) before fp8_linear (layers.py:158-159)
+                bb = bb.to(torch.float8_e4m3fn).to(torch.bfloat16)
+            bb = bb.to(torch.float32)
+        return _Lin(wq, bb, fp8=True)
 
     def quantize_fp8_rows(self, x):
         """AutoWrappedLinear.fp8_linear lines 126-136 on bf16-representable x [M, K]: (e4m3 tensor, fp32 scale [M])."""

@@ -12,7 +12,7 @@ from fantasy_world_amd import hip_ops
 
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "fw_mi355x.h")).read()
-    return sorted(set(re.findall(r"^\s*(?:int|const char\*)\s+(fw_[a-z0-9_]+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(fw_[a-z0-9_]+)\s*\(", txt, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip_ops.SYMBOLS) == declared, (sorted(hip_ops.SYMBOLS), declared)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.fw_abi_version() == 6
+    assert lib.fw_abi_version() == 7
 
 
 def test_no_cpu_fallback():

@@ -40,8 +40,12 @@ def test_fp8_linear_restatement_matches_reference_code(M, N, K, amp, monkeypatch
     monkeypatch.setattr(torch, "_scaled_mm", _scaled_mm_definition)
     want = wrapped.fp8_linear(x, lin.weight, lin.bias)
     ops = TorchRefOps()
-    got = ops.linear_fp8(x.float(), ops.pack_linear_fp8(lin.weight.float(), lin.bias.float()))
+    got = ops.linear_fp8(x.float(), ops.pack_linear_fp8(lin.weight.float(), lin.bias.float(), bias_through_fp8=False))
     assert want.dtype == torch.bfloat16 and want.shape == (M, N)
     assert torch.equal(got.to(torch.bfloat16), want), rel_l2(got, want.float())
     q, scale = ops.quantize_fp8_rows(x.float())
     assert scale.min() >= 1.0 and (amp < 1.0 or scale.max() > 1.0)
+    # through the MODULE (forward casts weight and bias to the computation dtype first, layers.py:158-159): the default packing
+    want_mod = wrapped(x)
+    got_mod = ops.linear_fp8(x.float(), ops.pack_linear_fp8(lin.weight.float(), lin.bias.float()))
+    assert torch.equal(got_mod.to(torch.bfloat16), want_mod), rel_l2(got_mod, want_mod.float())

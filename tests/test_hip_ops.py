@@ -90,34 +90,33 @@ def test_gemm_strided_views(ops, ref):
 
 # the 256x256 kernels (M >= 2048, N >= 1024): 5-deep half-slab ring (default) and the 2-stage staggered kernel accumulate
 # in the same k order, so they must agree BIT FOR BIT with each other, and with the fp32 reference to rounding.
-RING_SHAPES = [(2048, 1024, 256), (2300, 1280, 320), (4095, 1152, 1024), (2051, 2304, 576), (2560, 1024, 4096)]
+RING_SHAPES = [(2048, 1024, 256), (2300, 1280, 320), (4095, 1152, 1024), (2051, 2304, 576), (2560, 1024, 4096),
+               (2304, 1280, 2048), (4096 + 97, 1536, 1344)]
 
 
 @pytest.mark.parametrize("M,N,K", RING_SHAPES)
-def test_gemm_ring_kernel_shapes(ops, ref, M, N, K):
+def test_gemm_big_tile_kernels_agree(ops, ref, M, N, K, parity):
+    """The two 256x256 kernels -- 8-wave ping-pong (default) and four-wave 128x128-wave-tile (short K; FW_GEMM_KERNEL=5 forces
+    it) -- against the fp32 reference and against each other: same k-order per output element, so they agree BIT FOR BIT."""
     x, w, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23, scale=0.1)
     want = ref.linear(x, ref.pack_linear(w, b), out_f32=True)
     lin = ops.pack_linear(w, b)
     xd = bf(x).cuda()
     try:
         outs = {}
-        for kern in (1, 0, 2, 3):
+        for kern in (4, 5):
             ops.set_option("gemm_kernel", kern)
-            for var in {1: (0, 1, 8), 0: (0,), 2: (0,), 3: (0, 1)}[kern]:
-                ops.set_option("gemm_var", var)
-                outs[(kern, var)] = ops.linear(xd, lin, out_f32=True)
+            outs[kern] = ops.linear(xd, lin, out_f32=True)
         torch.cuda.synchronize()
     finally:
-        ops.set_option("gemm_kernel", 3)
-        ops.set_option("gemm_var", 1)
-    assert rel_l2(outs[(3, 1)], want) < 1e-3
-    for key, o in outs.items():
-        assert torch.equal(o, outs[(3, 1)]), key
+        ops.set_option("gemm_kernel", 4)
+    parity.check(f"op/gemm_big_f32out/{M}x{N}x{K}", rel_l2(outs[4], want), 1e-3)
+    assert torch.equal(outs[5], outs[4])
 
 
-@pytest.mark.parametrize("kern", [1, 2, 3])
+@pytest.mark.parametrize("kern", [4, 5])
 @pytest.mark.parametrize("res_dtype,out_f32", [("f32", True), ("bf16", False)])
-def test_gemm_ring_kernel_fused_epilogue(ops, ref, res_dtype, out_f32, kern):
+def test_gemm_big_tile_fused_epilogue(ops, ref, res_dtype, out_f32, kern, parity):
     """gelu + per-column affine + residual on the big-tile path, ragged M and N tails, in place on the residual."""
     M, N, K = 2333, 1028, 512
     x, w, b = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33, scale=0.1)
@@ -131,8 +130,8 @@ def test_gemm_ring_kernel_fused_epilogue(ops, ref, res_dtype, out_f32, kern):
                          out_f32=out_f32, out=r)
         torch.cuda.synchronize()
     finally:
-        ops.set_option("gemm_kernel", 3)
-    assert rel_l2(got.float(), want) < (1e-3 if out_f32 else 4e-3)
+        ops.set_option("gemm_kernel", 4)
+    parity.check(f"op/gemm_big_epilogue/k{kern}/{res_dtype}", rel_l2(got.float(), want), 1e-3 if out_f32 else 4e-3)
 
 
 def test_gemm_rejects_bad_k(ops):
@@ -157,12 +156,11 @@ def test_gemv_f32(ops, ref):
 DEFAULT_ATTN_VAR = 192
 
 
-@pytest.fixture(params=[0, 18, 34, 64, 65, 128, 129, 131, 161, 163, 192],
-                ids=["attn_v0", "attn_pp4_defer", "attn_pp2", "attn_pp3", "attn_pp3_dmaqk", "attn_sp", "attn_sp_pinned",
-                     "attn_sp_w4", "attn_sp_pair", "attn_sp_w4_pair", "attn_default"])
+@pytest.fixture(params=[0, 64, 129, 131, 192], ids=["attn_v0", "attn_pp3", "attn_sp", "attn_sp_w4", "attn_default"])
 def attn_variant(ops, request):
-    """Every attention test runs on the first kernel (0), on the 4- and 2-segment ping-pong kernels, and on the fast
-    log2-domain kernel (64+), which is selected when q carries the softmax scale (q_prescaled=True)."""
+    """Every attention test runs on the generic first kernel (0), on the two-segment ping-pong kernel (64), on the single-stream
+    kernel in its 8-wave (129) and 4-wave (131) forms, and on the default per-head-dim choice (192); 64+ are selected when q
+    carries the softmax scale (q_prescaled=True)."""
     ops.set_option("attn_var", request.param)
     yield request.param
     ops.set_option("attn_var", DEFAULT_ATTN_VAR)
@@ -188,6 +186,36 @@ def test_attention_matches_softmax_reference(attn_variant, ops, ref, heads, hd, 
     want = ref.attention(q, k, v, heads, hd, batch=batch, q_prescaled=pre)
     got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, batch=batch, q_prescaled=pre)
     assert rel_l2(got.float(), want) < 4e-3
+
+
+@pytest.mark.parametrize("heads,hd,Lq,Lk", [(12, 96, 256 * 64 + 97, 1100), (16, 64, 256 * 16 + 30, 2048), (40, 128, 256 * 32 + 5, 1030)])
+def test_attention_split_kv_tail(ops, ref, heads, hd, Lq, Lk, parity):
+    """Tail q-block through split-KV (the launcher takes the route when the tail work-groups would cost an extra round of the
+    256 CUs and the caller passes a workspace): the tail rows against the fp32 reference, the whole output against the
+    single-launch path, the accumulate flag, and a spiked key in one run (its shift differs from the other runs' by ~2^100)."""
+    assert ops.lib.fw_attention_workspace_bytes(1, heads, hd, Lq, Lk) > 0
+    assert ops.lib.fw_attention_workspace_bytes(1, heads, hd, Lq - Lq % 256, Lk) == 0
+    g = torch.Generator(device="cuda").manual_seed(11)
+    D = heads * hd
+    q = (torch.randn(Lq, D, device="cuda", generator=g) * ops.q_scale(hd)).to(torch.bfloat16)
+    k = torch.randn(Lk, D, device="cuda", generator=g).to(torch.bfloat16)
+    v = torch.randn(Lk, D, device="cuda", generator=g).to(torch.bfloat16)
+    k[Lk - 40, :hd] = (q[Lq - 3, :hd].float() * 60.0).to(torch.bfloat16)      # head 0: a late key far above everything else for one tail row
+    got = ops.attention(q, k, v, heads, hd, q_prescaled=True)
+    try:
+        ops.split_kv = False
+        base = ops.attention(q, k, v, heads, hd, q_prescaled=True)
+    finally:
+        ops.split_kv = True
+    tail0 = Lq - Lq % 256
+    assert torch.equal(got[:tail0], base[:tail0])                             # the full q-blocks are the same launch either way
+    rows = torch.arange(tail0, Lq, device="cuda")
+    want = ref.attention(q[rows].float().cpu(), k.float().cpu(), v.float().cpu(), heads, hd, q_prescaled=True)
+    parity.check(f"op/attention_split_kv_tail/hd{hd}", rel_l2(got[rows].float(), want), 4e-3)
+    parity.check(f"op/attention_single_launch_tail/hd{hd}", rel_l2(base[rows].float(), want), 4e-3)
+    acc = got.clone()
+    ops.attention(q, k, v, heads, hd, out=acc, accumulate=True, q_prescaled=True)
+    assert rel_l2(acc[rows].float(), 2 * want) < 5e-3
 
 
 def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref):

@@ -156,3 +156,106 @@ def test_install_vae_keeps_reference_tiling():
     undo()
     with torch.no_grad():
         assert torch.equal(vae.decode(z, device="cpu", tiled=False), want1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the finer-grained B3 hooks (fantasy_world_amd/hooks.py) on the REAL reference modules, CPU op set
+# ---------------------------------------------------------------------------------------------------------------
+def test_bicross_attention_hook_b3():
+    """BiMultiHeadAttention.attn_implementation / forward_sdpa (fusion/layer/block.py:323-325,393-410,532-625): the reference
+    module keeps its projections and RoPE, the two SDPA calls go through the engine's attention op."""
+    from oracle import ref_harness, fw_oracle
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install_bicross_attention
+    ref_harness.install_stubs()
+    from FantasyWorld.fusion.layer.block import BiMultiHeadAttention, CrossModalityBiAttentionBlock
+    torch.manual_seed(0)
+    blk = CrossModalityBiAttentionBlock(64, 32, 192, 2).eval()                 # 2 heads x 96, like the real 12 x 96
+    with torch.no_grad():
+        blk.gamma_m1.normal_()
+        blk.gamma_m2.normal_()
+    f, h, w, ns = 2, 3, 4, 5
+    fb = fw_oracle.precompute_freqs_cis_3d(96)
+    fd, fa = fw_oracle.expand_freqs(fb, f, h, w), fw_oracle.build_freqs_3d_with_extra_cis(fb, f, h, w, ns)
+    x1, x2 = torch.randn(1, f * h * w, 64), torch.randn(1, f * (ns + h * w), 32)
+    with torch.no_grad():
+        want = blk([x1, x2], freqs=None, freqs_dit=fd, freqs_agg=fa)
+    calls = []
+    ops = TorchRefOps()
+    orig = ops.attention
+    ops.attention = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+    undo = install_bicross_attention(blk, ops=ops)
+    try:
+        assert isinstance(blk.cross_attn, BiMultiHeadAttention) and blk.cross_attn.attn_implementation == "sdpa"
+        with torch.no_grad():
+            got = blk([x1, x2], freqs=None, freqs_dit=fd, freqs_agg=fa)
+        assert len(calls) == 2
+        for g_, w_ in zip(got, want):
+            assert g_.shape == w_.shape and rel_l2(g_, w_) < 1e-5
+    finally:
+        undo()
+    with torch.no_grad():
+        again = blk([x1, x2], freqs=None, freqs_dit=fd, freqs_agg=fa)
+    assert all(torch.equal(a, b) for a, b in zip(again, want)) and "forward_sdpa" not in blk.cross_attn.__dict__
+
+
+def test_layernorm_kernel_hook_b3():
+    """get_layernorm(use_kernel=True) (fusion/layer/block.py:693-708; apex FusedLayerNorm in the reference) builds a HipLayerNorm:
+    CrossModalityBiAttentionBlock(enable_layernorm_kernel=True) constructs and computes what the nn.LayerNorm version does."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install_layernorm_kernel, HipLayerNorm
+    ref_harness.install_stubs()
+    import FantasyWorld.fusion.layer.block as block
+    original = block.get_layernorm
+    undo = install_layernorm_kernel(block, ops=TorchRefOps())
+    try:
+        torch.manual_seed(1)
+        a = block.CrossModalityBiAttentionBlock(64, 32, 192, 2, enable_layernorm_kernel=True).eval()
+        assert isinstance(a.attn_norm_m1, HipLayerNorm) and a.attn_norm_m1.weight is None and a.attn_norm_m1.eps == 1e-6
+        ln = block.get_layernorm(48, 1e-5, True, True)
+        with torch.no_grad():
+            ln.weight.normal_()
+            ln.bias.normal_()
+        x = torch.randn(3, 7, 48)
+        want = torch.nn.functional.layer_norm(x, (48,), ln.weight, ln.bias, 1e-5)
+        assert rel_l2(ln(x), want) < 1e-6
+        assert isinstance(block.get_layernorm(48, 1e-5, True, False), torch.nn.LayerNorm)
+    finally:
+        undo()
+    assert block.get_layernorm is original
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_hip_linear_in_enable_vram_management_module_map(fp8, monkeypatch):
+    """The reference's module swap (diffsynth_wan21/vram_management/layers.py:145-166) with HipLinear as the target of nn.Linear:
+    same outputs as the reference's own AutoWrappedLinear, in bf16 and -- computation_dtype float8_e4m3fn -- as fp8_linear
+    (diffsynth_wan22/vram_management/layers.py:115-151; torch._scaled_mm replaced by its definition, as in tests/test_fp8_cpu.py)."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import HipLinear
+    ref_harness.install_stubs()
+    from FantasyWorld.diffsynth_wan22.vram_management.layers import AutoWrappedLinear, enable_vram_management
+
+    def build():
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(96, 128), torch.nn.GELU(), torch.nn.Linear(128, 40)).bfloat16()
+        return net
+    cdt = torch.float8_e4m3fn if fp8 else torch.bfloat16
+    cfg = dict(offload_dtype=torch.bfloat16, offload_device="cpu", onload_dtype=torch.bfloat16, onload_device="cpu",
+               computation_dtype=cdt, computation_device="cpu")
+    ref_net, hip_net = build(), build()
+    enable_vram_management(ref_net, {torch.nn.Linear: AutoWrappedLinear}, cfg)
+    enable_vram_management(hip_net, {torch.nn.Linear: HipLinear}, dict(cfg, ops=TorchRefOps(emulate_bf16=True)))
+    assert isinstance(hip_net[0], HipLinear) and hip_net[0].enable_fp8 == fp8 and hip_net.vram_management_enabled
+    if fp8:
+        monkeypatch.setattr(torch, "_scaled_mm", lambda a, b, scale_a=None, scale_b=None, bias=None, out_dtype=None, **kw:
+                            ((a.float() @ b.float()) * scale_a.float() * scale_b.float() + bias.float()).to(out_dtype))
+    x = torch.randn(2, 5, 96).bfloat16()
+    with torch.no_grad():
+        one_want, one_got = ref_net[0](x), hip_net[0](x)
+        want, got = ref_net(x), hip_net(x)
+    assert one_got.dtype == one_want.dtype and rel_l2(one_got.float(), one_want.float()) < (1e-6 if fp8 else 4e-3), rel_l2(one_got.float(), one_want.float())
+    assert got.shape == want.shape and got.dtype == want.dtype
+    # chained: a bf16 rounding difference of the hidden activation can flip an e4m3 quantisation step of the second layer
+    assert rel_l2(got.float(), want.float()) < (3e-2 if fp8 else 6e-3)

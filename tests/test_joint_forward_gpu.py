@@ -206,8 +206,9 @@ def test_hip_matches_cpu_oracle_on_negative_prompt_and_uncond(case_l2):
 def test_full_size_forward_agrees_across_independent_kernels(flavour, grid):
     """BASELINE sizes (config 2: 81f x 480 x 832 -> L = 32760; config 4: 81f x 720p -> L = 75600) on a 2-block model: too big
     for the CPU oracle, so the size-independent check is agreement between INDEPENDENT implementations of the hot kernels --
-    the default path (ping-pong GEMM, log2-domain two-segment attention) against the first-generation kernels (2-stage GEMM,
-    single-segment attention with per-tile max): different tilings, schedules, DMA layouts and softmax algebra, same math.
+    the default path (8-wave ping-pong GEMM, log2-domain single-stream attention) against the four-wave GEMM (128x128 wave
+    tiles, its own DMA order and epilogue) and the first-generation attention kernel (per-tile running max): different tilings,
+    schedules, DMA layouts and softmax algebra, same math.
     Catches size-dependent addressing bugs (32-bit offsets, tail tiles, ring wrap-around) that small goldens cannot."""
     from fantasy_world_amd import config as fwc, synth
     from fantasy_world_amd.engine import FusionEngine
@@ -226,15 +227,13 @@ def test_full_size_forward_agrees_across_independent_kernels(flavour, grid):
     a, _ = eng.joint_forward(ins["x"], t, ins["context"], **kw)
     torch.cuda.synchronize()
     try:
-        ops.set_option("gemm_kernel", 0)
-        ops.set_option("gemm_var", 0)
+        ops.set_option("gemm_kernel", 5)
         ops.set_option("attn_var", 0)
         b, _ = eng.joint_forward(ins["x"], t, ins["context"], **kw)
         torch.cuda.synchronize()
     finally:
-        ops.set_option("gemm_kernel", 3)
-        ops.set_option("gemm_var", 1)
-        ops.set_option("attn_var", 64)
+        ops.set_option("gemm_kernel", 4)
+        ops.set_option("attn_var", 192)
     assert torch.isfinite(a.float()).all() and torch.isfinite(b.float()).all()
     err = rel_l2(a.float(), b.float())
     print(flavour, grid, f"default vs baseline kernels rel-L2 = {err:.2e}")
@@ -323,3 +322,80 @@ def test_flash_attention_hook_on_hip():
     assert rel_l2(out.float(), want.transpose(1, 2).reshape(b, lq, heads * hd)) < 4e-3
     undo()
     assert mod.flash_attention is None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# finer-grained B3 hooks (fantasy_world_amd/hooks.py) on the GPU.  The reference tree does not exist on the GPU box, so the
+# modules below are stand-ins with the reference's attribute names and arithmetic (the hooks are duck-typed: they look for a
+# class called BiMultiHeadAttention and call its projections); the REAL reference modules run through the same hooks on the CPU
+# op set in tests/test_install_dropin.py.
+# ---------------------------------------------------------------------------------------------------------------
+class BiMultiHeadAttention(torch.nn.Module):
+    """fusion/layer/block.py:315-625 reduced to what forward_sdpa touches (no RoPE: freqs_dit=None)."""
+
+    def __init__(self, m1_dim, m2_dim, embed_dim, num_heads):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.m1_proj, self.m2_proj = torch.nn.Linear(m1_dim, embed_dim), torch.nn.Linear(m2_dim, embed_dim)
+        self.values_m1_proj, self.values_m2_proj = torch.nn.Linear(m1_dim, embed_dim), torch.nn.Linear(m2_dim, embed_dim)
+        self.out_m1_proj, self.out_m2_proj = torch.nn.Linear(embed_dim, m1_dim), torch.nn.Linear(embed_dim, m2_dim)
+        self.attn_implementation = "sdpa"
+
+    def forward(self, x1, x2, **kw):
+        return self.forward_sdpa(x1, x2, **kw)
+
+    def forward_sdpa(self, x1, x2, attention_mask_1=None, attention_mask_2=None, freqs=None, freqs_dit=None, freqs_agg=None):
+        b, L1, _ = x1.shape
+        L2 = x2.shape[1]
+        sh = lambda t, n: t.view(b, n, self.num_heads, self.head_dim).transpose(1, 2)
+        q, k = sh(self.m1_proj(x1), L1), sh(self.m2_proj(x2), L2)
+        v1, v2 = sh(self.values_m1_proj(x1), L1), sh(self.values_m2_proj(x2), L2)
+        o1 = torch.nn.functional.scaled_dot_product_attention(q, k, v2).transpose(1, 2).reshape(b, L1, self.embed_dim)
+        o2 = torch.nn.functional.scaled_dot_product_attention(k, q, v1).transpose(1, 2).reshape(b, L2, self.embed_dim)
+        return self.out_m1_proj(o1), self.out_m2_proj(o2)
+
+
+def test_b3_hooks_on_hip(parity):
+    from fantasy_world_amd import install_bicross_attention, HipLayerNorm, HipLinear
+    from fantasy_world_amd.hip_ops import HipOps
+    ops = HipOps("cuda:0")
+    torch.manual_seed(0)
+    # bicross attention: 12 heads x 96 like the real block, both directions
+    m = BiMultiHeadAttention(256, 128, 1152, 12).cuda().eval()
+    x1, x2 = torch.randn(1, 700, 256, device="cuda"), torch.randn(1, 333, 128, device="cuda")
+    with torch.no_grad():
+        want = m(x1, x2)
+        undo = install_bicross_attention(m, ops=ops)
+        got = m(x1, x2)
+        undo()
+        again = m(x1, x2)
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        parity.check(f"hook/bicross_attention/out{i + 1}", rel_l2(g_, w_), 6e-3)      # bf16 q/k/v/P against fp32 SDPA
+    assert all(torch.equal(a, b) for a, b in zip(again, want))
+    # LayerNorm kernel hook
+    ln = HipLayerNorm(5120, eps=1e-6, elementwise_affine=False, ops=ops)
+    x = torch.randn(3, 50, 5120, device="cuda")
+    parity.check("hook/layernorm_noaffine", rel_l2(ln(x), torch.nn.functional.layer_norm(x, (5120,), None, None, 1e-6)), 4e-3)
+    lna = HipLayerNorm(1024, eps=1e-5, elementwise_affine=True, ops=ops).cuda()
+    with torch.no_grad():
+        lna.weight.normal_()
+        lna.bias.normal_()
+    xa = torch.randn(70, 1024, device="cuda")
+    parity.check("hook/layernorm_affine", rel_l2(lna(xa), torch.nn.functional.layer_norm(xa, (1024,), lna.weight, lna.bias, 1e-5)), 4e-3)
+    # nn.Linear module-map target, bf16 and fp8 computation dtypes
+    lin = torch.nn.Linear(200, 320).cuda().bfloat16()              # K = 200: padded to 256 inside
+    xl = torch.randn(4, 33, 200, device="cuda").bfloat16()
+    hl = HipLinear(lin, computation_dtype=torch.bfloat16, computation_device="cuda", ops=ops)
+    with torch.no_grad():
+        want = torch.nn.functional.linear(xl.float(), lin.weight.float(), lin.bias.float())
+        got = hl(xl)
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape
+    parity.check("hook/hip_linear_bf16", rel_l2(got.float(), want), 4e-3)
+    h8 = HipLinear(lin, computation_dtype=torch.float8_e4m3fn, computation_device="cuda", ops=ops)
+    from oracle.ref_ops import TorchRefOps
+    ref = TorchRefOps()
+    w8 = ref.linear_fp8(xl.float().cpu().reshape(-1, 200), ref.pack_linear_fp8(lin.weight.float().cpu(), lin.bias.float().cpu()),
+                        out_f32=True)
+    with torch.no_grad():
+        g8 = h8(xl)
+    parity.check("hook/hip_linear_fp8", rel_l2(g8.float().reshape(-1, 320), w8), 4e-3)

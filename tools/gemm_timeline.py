@@ -44,5 +44,5 @@ for var in (2,):
             print("    slab", 16 + sl, " | ".join(row))
     span = buf[3 * 8 + 6] - buf[0]
     print(f"  4 slabs (group A LOAD0(16) start -> MFMA1(19) start): {span} ticks")
-ops.set_option("gemm_kernel", 3)
-ops.set_option("gemm_var", 1)
+ops.set_option("gemm_kernel", 4)
+ops.set_option("gemm_var", 0)
