@@ -156,6 +156,9 @@ class FusionEngine:
         cam = g("vggt.aggregator.camera_token")[0]        # [2,1,C]
         reg = g("vggt.aggregator.register_token")[0]      # [2,4,C]
         self.special = ops.to_f32(torch.cat([cam, reg], dim=1))   # [2, n_special, C]
+        ctp = "vggt.aggregator.CamTokenProjector.mlp."             # only used when the caller passes camera_token
+        self.camtok0 = lin(ctp + "0.weight", ctp + "0.bias", k_pad=64)          # 36 -> 128 (K padded to 64)
+        self.camtok2 = lin(ctp + "2.weight", ctp + "2.bias")
         self.vtime0 = ops.pack_linear_f32(g("vggt.time_embedding.0.weight"), g("vggt.time_embedding.0.bias"))
         self.vtime2 = ops.pack_linear_f32(g("vggt.time_embedding.2.weight"), g("vggt.time_embedding.2.bias"))
         self.vtimep = ops.pack_linear_f32(g("vggt.time_projection.1.weight"), g("vggt.time_projection.1.bias"))
@@ -493,9 +496,6 @@ class FusionEngine:
         `collect`: optional dict that receives intermediate tensors (tests).
         """
         cfg, ops, sh = self.cfg, self.ops, self.shard
-        if camera_token is not None:
-            raise NotImplementedError("camera_token != None (CamTokenProjector path) is not used by the reference "
-                                      "inference scripts and is not implemented")
         assert x.shape[0] == 1, "the reference samples with batch 1 (model_wan21.py:254-258)"
         F, H2, W2 = x.shape[2:]
         h, w = H2 // 2, W2 // 2
@@ -561,6 +561,17 @@ class FusionEngine:
         else:
             S_loc = F
         tok = ops.assemble_tokens(ptok, self._special_for(sh), S_loc, hw)                      # fp32 [S_loc*P, C]
+        if camera_token is not None:
+            # CamTokenProjector (vggt/layers/block.py:276-297, aggregator.py:265-266): the learned camera token of every frame is
+            # replaced by an MLP of 4 consecutive pose encodings (the sequence is padded with 3 copies of its first pose)
+            ct = ops.to_act(camera_token[0])                                                   # [V, 9]
+            ct = torch.cat([ct, ct[:1].expand(3, -1)], dim=0).reshape(-1, 36)                   # [S, 36]
+            assert ct.shape[0] == F, (camera_token.shape, F)
+            ct = _pad_to(ct, 1, 64)
+            cam = ops.linear(ops.linear(ct, self.camtok0, act="gelu_erf"), self.camtok2, out_f32=True)     # fp32 [S, C]
+            if sh is not None:
+                cam = cam[sh.first_frame:sh.first_frame + S_loc]
+            tok.view(S_loc, P, cfg.vggt_dim)[:, 0, :] = cam
         if collect is not None:
             collect["tokens_in"] = tok.clone()
 

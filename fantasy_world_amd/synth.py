@@ -106,6 +106,9 @@ def weight_spec(cfg: FWConfig) -> "OrderedDict[str, tuple]":
     spec["vggt.projection_head.bias"] = ((c,), ("normal", 0.02))
     spec["vggt.aggregator.camera_token"] = ((1, 2, 1, c), ("normal", 0.5))
     spec["vggt.aggregator.register_token"] = ((1, 2, cfg.n_special - 1, c), ("normal", 0.5))
+    # CamTokenProjector (vggt/layers/block.py:276-297): 4 poses x 9 -> 128 -> C, only used when joint_forward gets camera_token
+    _lin(spec, "vggt.aggregator.CamTokenProjector.mlp.0", 128, 36)
+    _lin(spec, "vggt.aggregator.CamTokenProjector.mlp.2", c, 128)
     _lin(spec, "vggt.time_embedding.0", c, cfg.freq_dim)
     _lin(spec, "vggt.time_embedding.2", c, c)
     _lin(spec, "vggt.time_projection.1", 6 * c, c)
@@ -178,6 +181,8 @@ def make_inputs(cfg: FWConfig, f: int, h2: int, w2: int, seed=1, device="cpu", d
         # Wan2.2: Pluecker map folded to 24 channels at pixel resolution (inference_wan22.py:204-218): [1, 24, f, 8*h2, 8*w2]
         control_camera_latents_input=r(1, cfg.control_in_dim, f, 8 * h2, 8 * w2) if cfg.control_adapter else None,
         timestep=torch.tensor([timestep], dtype=torch.float32),
+        # optional camera_token [1, 4 (f - 1) + 1, 9] (one pose encoding per video frame; CamTokenProjector groups 4 per latent frame)
+        camera_token=r(1, 4 * (f - 1) + 1, 9),
     )
     lens = torch.ones(f, dtype=torch.long)
     lens[1:] = 4

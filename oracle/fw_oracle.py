@@ -275,17 +275,18 @@ def control_adapter(ctl, W, pre):
 
 
 def joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
-                  plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None, fp8_linears=False):
+                  plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None, fp8_linears=False,
+                  camera_token=None):
     _FP8["on"] = bool(fp8_linears)
     try:
         return _joint_forward(W, cfg, x, timestep, context, clip_feature, y, plucker_fea, plucker_context_lens, uncond, collect,
-                              control_camera_latents_input)
+                              control_camera_latents_input, camera_token)
     finally:
         _FP8["on"] = False
 
 
 def _joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, plucker_fea=None,
-                   plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None):
+                   plucker_context_lens=None, uncond=False, collect=None, control_camera_latents_input=None, camera_token=None):
     """W: name -> fp32 tensor (reference parameter names). Returns noise_pred [1,16,F,H,W] (fp32).
     Pass collect={"output_list": {}} to receive the aggregator's output_list (layer -> [f, P, 2C]), the input of the geometry
     heads (oracle/fw_heads_oracle.py restates VGGT._head_predction on it)."""
@@ -339,7 +340,15 @@ def _joint_forward(W, cfg, x, timestep, context, clip_feature=None, y=None, pluc
     def sef(tok):   # slice_expand_and_flatten, aggregator.py:283-306 (B = 1)
         return torch.cat([tok[:, 0:1], tok[:, 1:].expand(1, f - 1, *tok.shape[2:])], dim=1)[0]
 
-    tokens = torch.cat([sef(cam), sef(reg), pt], dim=1)                      # [f, P, C]
+    cam_tok = sef(cam)
+    if camera_token is not None:
+        # CamTokenProjector.forward (vggt/layers/block.py:286-297; aggregator.py:265-266): pad with 3 copies of the first pose,
+        # group 4 poses x 9 numbers per latent frame, MLP 36 -> 128 -> GELU(erf) -> C: one camera token per frame
+        pre = "vggt.aggregator.CamTokenProjector.mlp."
+        c = torch.cat([camera_token, camera_token[:, :1].repeat(1, 3, 1)], dim=1)
+        c = c.view(1, c.shape[1] // 4, 36).flatten(0, 1)
+        cam_tok = linear(F.gelu(linear(c, W, pre + "0")), W, pre + "2").view(-1, 1, cfg.vggt_dim)
+    tokens = torch.cat([cam_tok, sef(reg), pt], dim=1)                       # [f, P, C]
     P = tokens.shape[1]
     ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
     pos = torch.stack([ys.reshape(-1), xs.reshape(-1)], dim=-1) + 1

@@ -25,6 +25,9 @@ CASES = {
     "wan21_l3_f2_12x8": (dict(num_layers=3, start_index=1), (2, 12, 8), 937.5, 512, False),
     # Wan2.2-Fun-A14B-Control-Camera flavour (model_wan22.py): control adapter in patchify, text-only context, no per-block adapter
     "wan22_l2_f2_8x12": (dict(num_layers=2, start_index=1), (2, 8, 12), 968.75, 512, False),
+    # camera_token given: VGGT's per-frame camera token comes from CamTokenProjector instead of the learned parameter
+    # (aggregator.py:265-266) -- not used by the inference scripts, part of the joint_forward signature
+    "wan21_camtok_l2_f3_8x8": (dict(num_layers=2, start_index=1), (3, 8, 8), 250.0, 512, False),
 }
 
 
@@ -42,7 +45,7 @@ def rel(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm()).item()
 
 
-def run_reference(cfg, W, ins, uncond=False):
+def run_reference(cfg, W, ins, uncond=False, camera_token=None):
     model = (ref_harness.build_reference_wan22 if cfg.control_adapter else ref_harness.build_reference_wan21)(cfg, weights=W)
     cap = {}
 
@@ -64,7 +67,7 @@ def run_reference(cfg, W, ins, uncond=False):
         else:
             out, pred = model.joint_forward(
                 ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"],
-                y=ins["y"], use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+                y=ins["y"], use_gradient_checkpointing=False, camera_token=camera_token, plucker_fea=ins["plucker_fea"],
                 plucker_context_lens=ins["plucker_context_lens"], uncond=uncond, return_prediction=False)
     assert pred is None
     cap["noise_pred"] = out.detach().clone()
@@ -84,7 +87,8 @@ def main():
         ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=ts, text_len=tl)
         print(f"[{name}] weights {sum(v.numel() for v in W.values())/1e9:.2f} B params in {time.time()-t0:.1f}s")
         t0 = time.time()
-        ref, model = run_reference(cfg, W, ins, uncond)
+        camtok = ins["camera_token"] if "camtok" in name else None
+        ref, model = run_reference(cfg, W, ins, uncond, camera_token=camtok)
         print(f"[{name}] reference forward {time.time()-t0:.1f}s; unused synth names: {model._fw_unused[:5]} "
               f"(n={len(model._fw_unused)}); hot-path names missing from synth: "
               f"{[m for m in model._fw_missing if not _cold(m)][:8]}")
@@ -95,7 +99,7 @@ def main():
         t0 = time.time()
         orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
                                       ins["plucker_fea"], ins["plucker_context_lens"], uncond=uncond, collect=col,
-                                      control_camera_latents_input=ins.get("control_camera_latents_input"))
+                                      control_camera_latents_input=ins.get("control_camera_latents_input"), camera_token=camtok)
         print(f"[{name}] oracle forward {time.time()-t0:.1f}s")
         col["noise_pred"] = orc
         for k in ("x_after_pcb", "x_final", "tokens_final", "noise_pred"):
@@ -103,7 +107,8 @@ def main():
         # a second timestep draw through the negative-prompt context (the CFG pair of one denoise step)
         golden = {k: v.to(torch.float32).contiguous() for k, v in ref.items()}
         golden["meta"] = dict(cfg=ckw, grid=(f, h2, w2), timestep=ts, text_len=tl, uncond=uncond, seed_weights=0,
-                              seed_inputs=1, torch=torch.__version__, flavour="wan22" if cfg.control_adapter else "wan21")
+                              seed_inputs=1, torch=torch.__version__, flavour="wan22" if cfg.control_adapter else "wan21",
+                              camera_token=camtok is not None)
         path = os.path.join(ROOT, "tests", "golden", name + ".pt")
         torch.save(golden, path)
         print(f"[{name}] wrote {path} ({os.path.getsize(path)/1e6:.2f} MB)")

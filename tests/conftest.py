@@ -90,6 +90,12 @@ def case_w22():
 
 
 @pytest.fixture(scope="session")
+def case_camtok():
+    """joint_forward(camera_token=...) : per-frame camera tokens from CamTokenProjector (aggregator.py:265-266)."""
+    return Case("wan21_camtok_l2_f3_8x8")
+
+
+@pytest.fixture(scope="session")
 def case_cfg1():
     """BASELINE.json configs[0]: 2-block model on latents [1,16,9,64,64] (L = 9216, L2 = 9261); noise_pred in full, the streams
     as 64 sampled rows (golden["rows_dit"], golden["rows_agg"])."""
@@ -108,10 +114,22 @@ class ParityLog:
 
     def __init__(self):
         self.rows = {}
+        # Tight bounds = 1.5 x the value measured on MI355X (tools/make_parity_bounds.py from profiles/rNN/parity.json; the
+        # kernels are deterministic, so a measured value reproduces bit for bit on any gfx950).  The bound written in the test
+        # is the PHYSICAL one (what the arithmetic may cost at most); the tight one turns a silent regression inside it -- say
+        # 1.2e-3 -> 3.9e-3 under a 4e-3 bound -- into a failure.  Only applied on a GPU run.
+        self.tight = {}
+        path = os.path.join(GOLDEN_DIR, "parity_bounds_gpu.json")
+        if os.path.exists(path) and torch.cuda.is_available():
+            import json
+            self.tight = json.load(open(path))["bounds"]
 
     def check(self, name, value, bound):
-        self.rows[name] = {"measured": float(value), "bound": float(bound)}
-        assert value < bound, f"{name}: {value:.3e} >= {bound:.3e}"
+        tight = self.tight.get(name)
+        eff = float(bound) if tight is None else min(float(bound), float(tight))
+        self.rows[name] = {"measured": float(value), "bound": float(bound), "enforced": eff}
+        assert value < eff, f"{name}: {value:.3e} >= {eff:.3e} (physical bound {bound:.1e}" + (
+            "" if tight is None else f", 1.5 x measured {tight:.3e}") + ")"
         return value
 
     def note(self, name, value):
@@ -153,6 +171,8 @@ def forward_kwargs(case, dev=None):
               plucker_context_lens=mv(ins["plucker_context_lens"]), uncond=case.uncond)
     if ins.get("control_camera_latents_input") is not None:
         kw["control_camera_latents_input"] = mv(ins["control_camera_latents_input"])
+    if case.golden["meta"].get("camera_token"):
+        kw["camera_token"] = mv(ins["camera_token"])
     return kw
 
 

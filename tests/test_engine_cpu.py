@@ -19,7 +19,7 @@ def _run(case, emulate_bf16):
     return col
 
 
-@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22"])
+@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22", "case_camtok"])
 def test_engine_fp32_matches_golden(case_name, request):
     case = request.getfixturevalue(case_name)
     col = _run(case, emulate_bf16=False)

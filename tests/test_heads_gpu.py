@@ -59,7 +59,7 @@ def test_im2col_is_an_exact_gather(ops, ref, T, H, W, C, kt, kh, kw, sh, sw, t0,
     assert torch.equal(got.float().cpu(), want)
 
 
-def test_im2col_then_gemm_is_the_convolution(ops):
+def test_im2col_then_gemm_is_the_convolution(ops, parity, request):
     """Tap-major gather + weight [N][kt][kh][kw][C] == F.conv3d with causal time padding (vae_modified.py:17-36)."""
     import torch.nn.functional as F
     T, H, W, C, N = 5, 6, 7, 64, 128
@@ -68,20 +68,20 @@ def test_im2col_then_gemm_is_the_convolution(ops):
     want = F.conv3d(F.pad(vol, (1, 1, 1, 1, 2, 0)), w, b)[0].permute(1, 2, 3, 0).reshape(T * H * W, N)
     lin = ops.pack_linear(w.permute(0, 2, 3, 4, 1).reshape(N, 27 * C), b)
     got = ops.linear(ops.im2col(dev(x), T, H, W, 3, 3, 3), lin, out_f32=True)
-    assert rel_l2(got, want) < 1e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-3)
 
 
 @pytest.mark.parametrize("N,h,w,H,W,C", [(2, 4, 6, 8, 12, 64), (1, 15, 26, 30, 52, 72), (3, 5, 3, 20, 12, 64), (1, 7, 7, 7, 7, 8),
                                          (2, 1, 5, 4, 9, 16)])
-def test_resize_bilinear_align_corners(ops, ref, N, h, w, H, W, C):
+def test_resize_bilinear_align_corners(ops, ref, N, h, w, H, W, C, parity, request):
     x = rnd(N * h * w, C, seed=5)
     want = ref.resize_bilinear(x, N, h, w, H, W)
     got = ops.resize_bilinear(dev(x), N, h, w, H, W)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
 @pytest.mark.parametrize("rows,C,c_true", [(301, 128, 96), (77, 64, 64), (1030, 256, 192), (50, 384, 384), (9, 1024, 1024)])
-def test_chan_rmsnorm_silu(ops, ref, rows, C, c_true):
+def test_chan_rmsnorm_silu(ops, ref, rows, C, c_true, parity, request):
     """Both kernels: several rows per wave for C = 64 / 128 / 256, one wave per row otherwise; ragged row counts."""
     x = rnd(rows, C, seed=6, scale=3.0)
     x[:, c_true:] = 0
@@ -89,11 +89,11 @@ def test_chan_rmsnorm_silu(ops, ref, rows, C, c_true):
     g[:c_true] = 1 + 0.1 * rnd(c_true, seed=7)
     want = ref.chan_rmsnorm_silu(x, g, c_true)
     got = ops.chan_rmsnorm_silu(dev(x), g.cuda(), c_true)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
     assert (got[:, c_true:] == 0).all()
 
 
-def test_depth_to_space_unfold_time_add_table_add_act(ops, ref):
+def test_depth_to_space_unfold_time_add_table_add_act(ops, ref, parity, request):
     N, h, w, k, C = 2, 3, 5, 4, 64
     y = rnd(N * h * w, k * k * C, seed=8)
     assert torch.equal(ops.depth_to_space(dev(y), N, h, w, k, C).float().cpu(), ref.depth_to_space(y, N, h, w, k, C))
@@ -103,17 +103,17 @@ def test_depth_to_space_unfold_time_add_table_add_act(ops, ref):
     x, tab = rnd(4 * hw, C, seed=10), rnd(hw, C, seed=11, scale=0.1)
     want = ref.add_table(x.clone(), tab)
     got = ops.add_table(dev(x), tab.cuda())
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
     a, b = rnd(77, C, seed=12), rnd(77, C, seed=13)
     for relu in (False, True):
-        assert rel_l2(ops.add_act(dev(a), dev(b), relu=relu).float(), ref.add_act(a, b, relu=relu)) < 4e-3
+        parity.check(f"op/{request.node.name}/1", rel_l2(ops.add_act(dev(a), dev(b), relu=relu).float(), ref.add_act(a, b, relu=relu)), 4e-3)
     assert torch.equal(ops.add_act(dev(a), None, relu=True).float().cpu(), torch.relu(a))
 
 
-def test_adaln_rows_and_head_activation(ops, ref):
+def test_adaln_rows_and_head_activation(ops, ref, parity, request):
     rows, C = 81, 256
     x, mod = rnd(rows, C, seed=14, scale=2.0), rnd(rows, 3 * C, seed=15, scale=0.5)
-    assert rel_l2(ops.adaln_rows(x.cuda(), mod.cuda()), ref.adaln_rows(x, mod)) < 1e-5
+    parity.check(f"op/{request.node.name}/0", rel_l2(ops.adaln_rows(x.cuda(), mod.cuda()), ref.adaln_rows(x, mod)), 1e-5)
     y = rnd(1000, 4, seed=16, scale=2.0)
     for mode in ("exp", "inv_log"):
         p, c = ops.head_activation(y.cuda(), mode)

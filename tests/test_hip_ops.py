@@ -41,25 +41,25 @@ GEMM_SHAPES = [(300, 200, 128), (1, 5120, 256), (257, 1280, 1280), (1000, 448, 2
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_plain_bf16_out(ops, ref, M, N, K):
+def test_gemm_plain_bf16_out(ops, ref, M, N, K, parity, request):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
     want = ref.linear(x, ref.pack_linear(w, b))
     got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b))
     assert got.dtype == torch.bfloat16 and got.shape == (M, N)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
 @pytest.mark.parametrize("act", ["relu", "gelu_tanh", "gelu_erf", "silu"])
-def test_gemm_activations(ops, ref, act):
+def test_gemm_activations(ops, ref, act, parity, request):
     M, N, K = 333, 384, 256
     x, w, b = rnd(M, K, seed=4), rnd(N, K, seed=5, scale=K ** -0.5), rnd(N, seed=6, scale=0.1)
     want = ref.linear(x, ref.pack_linear(w, b), act=act)
     got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), act=act, out_f32=True)
-    assert rel_l2(got, want) < 1e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-3)
 
 
 @pytest.mark.parametrize("res_dtype", ["f32", "bf16"])
-def test_gemm_affine_residual_epilogue(ops, ref, res_dtype):
+def test_gemm_affine_residual_epilogue(ops, ref, res_dtype, parity, request):
     """y = res + (acc+bias)*g1 + g0: gates (DIT21:246-251), LayerScale, VGGT post-MLP modulation (VB:78-81)."""
     M, N, K = 515, 1024, 4096
     x, w, b = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=K ** -0.5), rnd(N, seed=9, scale=0.1)
@@ -70,13 +70,13 @@ def test_gemm_affine_residual_epilogue(ops, ref, res_dtype):
     if res_dtype == "f32":
         got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), g1=g1.cuda(), g0=g0.cuda(), res=r, out_f32=True, out=r)
         assert got.data_ptr() == r.data_ptr()          # in place on the fp32 residual stream
-        assert rel_l2(got, want) < 1e-3
+        parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-3)
     else:
         got = ops.linear(bf(x).cuda(), ops.pack_linear(w, b), g1=g1.cuda(), g0=g0.cuda(), res=r, out=r)
-        assert rel_l2(got.float(), want) < 4e-3
+        parity.check(f"op/{request.node.name}/1", rel_l2(got.float(), want), 4e-3)
 
 
-def test_gemm_strided_views(ops, ref):
+def test_gemm_strided_views(ops, ref, parity, request):
     """A and C may be column slices of wider buffers (fused q|k|v, k|v projections)."""
     M, K, N = 200, 128, 256
     big = rnd(M, 3 * K, seed=13)
@@ -84,7 +84,7 @@ def test_gemm_strided_views(ops, ref):
     want = ref.linear(big[:, K:2 * K], ref.pack_linear(w, b), out_f32=True)
     outbuf = torch.zeros(M, 2 * N, dtype=torch.float32, device="cuda")
     ops.linear(bf(big).cuda()[:, K:2 * K], ops.pack_linear(w, b), out_f32=True, out=outbuf[:, N:])
-    assert rel_l2(outbuf[:, N:], want) < 1e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(outbuf[:, N:], want), 1e-3)
     assert outbuf[:, :N].abs().max().item() == 0.0
 
 
@@ -142,14 +142,14 @@ def test_gemm_rejects_bad_k(ops):
         ops.linear(x, lin)
 
 
-def test_gemv_f32(ops, ref):
+def test_gemv_f32(ops, ref, parity, request):
     K, N = 256, 5120
     x = torch.randn(K, generator=torch.Generator().manual_seed(1))
     w, b = torch.randn(N, K, generator=torch.Generator().manual_seed(2)) * K ** -0.5, torch.randn(N) * 0.1
     for silu_in, act in [(False, "silu"), (True, None)]:
         want = ref.linear_f32(x, ref.pack_linear_f32(w, b), silu_in=silu_in, act=act)
         got = ops.linear_f32(x.cuda(), ops.pack_linear_f32(w, b), silu_in=silu_in, act=act)
-        assert rel_l2(got, want) < 1e-5
+        parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-5)
 
 
 # --------------------------------------------------------------------------------------------------------- attention
@@ -180,16 +180,16 @@ ATTN_CASES = [  # heads, hd, batch, Lq, Lk
 
 
 @pytest.mark.parametrize("heads,hd,batch,Lq,Lk", ATTN_CASES)
-def test_attention_matches_softmax_reference(attn_variant, ops, ref, heads, hd, batch, Lq, Lk):
+def test_attention_matches_softmax_reference(attn_variant, ops, ref, heads, hd, batch, Lq, Lk, parity, request):
     q, k, v = rnd(batch * Lq, heads * hd, seed=1), rnd(batch * Lk, heads * hd, seed=2), rnd(batch * Lk, heads * hd, seed=3)
     q, pre = _prescale(ops, attn_variant, q, hd)
     want = ref.attention(q, k, v, heads, hd, batch=batch, q_prescaled=pre)
     got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, batch=batch, q_prescaled=pre)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
 @pytest.mark.parametrize("heads,hd,Lq,Lk", [(12, 96, 256 * 64 + 97, 1100), (16, 64, 256 * 16 + 30, 2048), (40, 128, 256 * 32 + 5, 1030)])
-def test_attention_split_kv_tail(ops, ref, heads, hd, Lq, Lk, parity):
+def test_attention_split_kv_tail(ops, ref, heads, hd, Lq, Lk, parity, request):
     """Tail q-block through split-KV (the launcher takes the route when the tail work-groups would cost an extra round of the
     256 CUs and the caller passes a workspace): the tail rows against the fp32 reference, the whole output against the
     single-launch path, the accumulate flag, and a spiked key in one run (its shift differs from the other runs' by ~2^100)."""
@@ -215,10 +215,10 @@ def test_attention_split_kv_tail(ops, ref, heads, hd, Lq, Lk, parity):
     parity.check(f"op/attention_single_launch_tail/hd{hd}", rel_l2(base[rows].float(), want), 4e-3)
     acc = got.clone()
     ops.attention(q, k, v, heads, hd, out=acc, accumulate=True, q_prescaled=True)
-    assert rel_l2(acc[rows].float(), 2 * want) < 5e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(acc[rows].float(), 2 * want), 5e-3)
 
 
-def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref):
+def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref, parity, request):
     """q/k/v as column slices of one fused buffer; second call accumulates (cross-attn text + image, DIT21:197-200)."""
     heads, hd, L, Lc = 4, 128, 200, 77
     D = heads * hd
@@ -230,13 +230,13 @@ def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref):
     g = bf(qkv).cuda()
     c = bf(ctx).cuda()
     got = ops.attention(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], heads, hd, q_prescaled=pre)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
     ops.attention(g[:, :D], c[:, :D], c[:, D:], heads, hd, out=got, accumulate=True, q_prescaled=pre)
-    assert rel_l2(got.float(), want2) < 5e-3
+    parity.check(f"op/{request.node.name}/1", rel_l2(got.float(), want2), 5e-3)
 
 
 @pytest.mark.parametrize("gain", [3.0, 40.0])
-def test_attention_large_score_spike(attn_variant, ops, ref, gain):
+def test_attention_large_score_spike(attn_variant, ops, ref, gain, parity, request):
     """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence (gain 40: the spike is
     ~2^900 above everything else in the exponent domain -- the probabilities of the stale max overflow to inf and the slow
     path has to recover), a row whose max is set in tile 0 and never changes, and a row whose scores are all very negative."""
@@ -250,10 +250,10 @@ def test_attention_large_score_spike(attn_variant, ops, ref, gain):
     want = ref.attention(q, k, v, heads, hd, q_prescaled=pre)
     got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, q_prescaled=pre)
     assert torch.isfinite(got.float()).all()
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
-def test_attention_all_scores_far_below_zero(attn_variant, ops, ref):
+def test_attention_all_scores_far_below_zero(attn_variant, ops, ref, parity, request):
     """Every score of every row is << 0 (q = -20 k-ish): exp2 of the unshifted scores underflows; the first-tile max must
     anchor the running max or the row sums vanish."""
     heads, hd, Lq, Lk = 2, 64, 96, 200
@@ -266,10 +266,10 @@ def test_attention_all_scores_far_below_zero(attn_variant, ops, ref):
     want = ref.attention(q, k, v, heads, hd, q_prescaled=pre)
     got = ops.attention(bf(q).cuda(), bf(k).cuda(), bf(v).cuda(), heads, hd, q_prescaled=pre)
     assert torch.isfinite(got.float()).all()
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
-def test_attention_full_length_properties(attn_variant, ops):
+def test_attention_full_length_properties(attn_variant, ops, parity, request):
     """BASELINE config-2 size (L = 32760, hd 128): rows of softmax sum to 1 => V = const gives O = const, and
     sampled query rows match an fp32 evaluation of the same rows."""
     heads, hd, L = 2, 128, 32760
@@ -289,7 +289,7 @@ def test_attention_full_length_properties(attn_variant, ops):
         sl = slice(h * hd, (h + 1) * hd)
         s = (qs[rows][:, sl].float() @ k[:, sl].float().t()) * sc
         want = torch.softmax(s, dim=-1) @ v[:, sl].float()
-        assert rel_l2(o[rows][:, sl].float(), want) < 6e-3
+        parity.check(f"op/{request.node.name}/0", rel_l2(o[rows][:, sl].float(), want), 6e-3)
 
 
 def test_attention_rejects_bad_head_dim(attn_variant, ops):
@@ -303,7 +303,7 @@ def test_attention_rejects_bad_head_dim(attn_variant, ops):
                                                    (1024, 129, True, True, "f32"), (1280, 257, True, False, "bf16"),
                                                    (5120, 5, True, False, "bf16"), (2048, 9, True, False, "f32"),
                                                    (1000, 7, True, True, "f32"), (8192, 3, False, True, "f32")])
-def test_layernorm_mod(ops, ref, C, rows, affine, mod, xdt):
+def test_layernorm_mod(ops, ref, C, rows, affine, mod, xdt, parity, request):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(rows, C, generator=g) * 3 + 0.5
     if xdt == "bf16":
@@ -317,10 +317,10 @@ def test_layernorm_mod(ops, ref, C, rows, affine, mod, xdt):
     cu = lambda t: None if t is None else t.cuda()
     xin = x.cuda().to(torch.bfloat16) if xdt == "bf16" else x.cuda()
     got = ops.layernorm(xin, cu(w), cu(b), cu(sc), cu(sh), eps)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
-def test_qk_prep_rms_full_rope3d(ops, ref):
+def test_qk_prep_rms_full_rope3d(ops, ref, parity, request):
     """DiT q/k: RMSNorm over the full 5120 width (DIT21:170-171) + interleaved 3-D RoPE (DIT21:97-102)."""
     from fantasy_world_amd import rope
     heads, hd = 40, 128
@@ -333,11 +333,11 @@ def test_qk_prep_rms_full_rope3d(ops, ref):
     ref.qk_prep(xr[:, heads * hd:2 * heads * hd], heads, hd, "rms_full", nw, None, 1e-6, "interleaved", tab)
     xg = bf(x).cuda()
     ops.qk_prep(xg[:, heads * hd:2 * heads * hd], heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab.cuda())
-    assert rel_l2(xg.float(), xr) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
     assert torch.equal(xg[:, :heads * hd].float().cpu(), x[:, :heads * hd])        # neighbours untouched
 
 
-def test_qk_prep_ln_head_rope2d(ops, ref):
+def test_qk_prep_ln_head_rope2d(ops, ref, parity, request):
     """VGGT q/k: per-head LayerNorm(64) (VA:43-44) + 2-D rotate-half RoPE base 100 (VR:154-188), table row = row % P."""
     from fantasy_world_amd import rope
     heads, hd, S, h, w = 16, 64, 3, 4, 5
@@ -350,10 +350,10 @@ def test_qk_prep_ln_head_rope2d(ops, ref):
     ref.qk_prep(xr, heads, hd, "ln_head", nw, nb, 1e-5, "half2d", tab)
     xg = bf(x).cuda()
     ops.qk_prep(xg, heads, hd, "ln_head", nw.cuda(), nb.cuda(), 1e-5, "half2d", tab.cuda())
-    assert rel_l2(xg.float(), xr) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
 
 
-def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref):
+def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref, parity, request):
     """bicross k: no norm, RoPE-3D hd=96 with 5 un-rotated special tokens per frame (DIT21:105-132)."""
     from fantasy_world_amd import rope
     heads, hd, f, h, w = 12, 96, 2, 3, 4
@@ -364,11 +364,11 @@ def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref):
     ref.qk_prep(xr, heads, hd, None, None, None, 1e-6, "interleaved", tab)
     xg = bf(x).cuda()
     ops.qk_prep(xg, heads, hd, None, None, None, 1e-6, "interleaved", tab.cuda())
-    assert rel_l2(xg.float(), xr) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
     assert torch.equal(xg[:5].float().cpu(), x[:5])                                # identity rows bit-exact
 
 
-def test_qk_prep_out_scale(ops, ref):
+def test_qk_prep_out_scale(ops, ref, parity, request):
     """out_scale is applied in fp32 before the single bf16 rounding (q carries softmax_scale*log2e into attention)."""
     from fantasy_world_amd import rope
     heads, hd, f, h, w = 40, 128, 1, 3, 4
@@ -379,16 +379,16 @@ def test_qk_prep_out_scale(ops, ref):
     ref.qk_prep(xr, heads, hd, "rms_full", nw, None, 1e-6, "interleaved", tab, out_scale=ops.q_scale(hd))
     xg = bf(x).cuda()
     ops.qk_prep(xg, heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab.cuda(), out_scale=ops.q_scale(hd))
-    assert rel_l2(xg.float(), xr) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
     # and through the generic (block-per-row) kernel: odd head count -> width not a multiple of 64 chunks is still wave path;
     # force the fallback with a misaligned table pointer
     tab2 = torch.cat([torch.zeros(1), tab.reshape(-1)]).cuda()[1:].view(tab.shape)
     xg2 = bf(x).cuda()
     ops.qk_prep(xg2, heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab2, out_scale=ops.q_scale(hd))
-    assert rel_l2(xg2.float(), xr) < 4e-3
+    parity.check(f"op/{request.node.name}/1", rel_l2(xg2.float(), xr), 4e-3)
 
 
-def test_qk_prep_rms_no_rope(ops, ref):
+def test_qk_prep_rms_no_rope(ops, ref, parity, request):
     heads, hd = 40, 128
     x = rnd(50, heads * hd, seed=12)
     nw = 1 + 0.1 * torch.randn(heads * hd, generator=torch.Generator().manual_seed(1))
@@ -396,7 +396,7 @@ def test_qk_prep_rms_no_rope(ops, ref):
     ref.qk_prep(xr, heads, hd, "rms_full", nw, None, 1e-6)
     xg = bf(x).cuda()
     ops.qk_prep(xg, heads, hd, "rms_full", nw.cuda(), None, 1e-6)
-    assert rel_l2(xg.float(), xr) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
 
 
 # --------------------------------------------------------------------------------------------------------- layout glue
@@ -410,7 +410,7 @@ def test_control_patchify_is_an_exact_gather(ops, ref, dtype):
     assert got.shape == (F_ * h * w, C * 256) and torch.equal(got.float().cpu(), want)
 
 
-def test_im2col3x3_is_an_exact_gather(ops, ref):
+def test_im2col3x3_is_an_exact_gather(ops, ref, parity, request):
     """3x3 / pad 1 im2col on token-major activations (ResidualBlock convs of the control adapter), zero borders, bit exact."""
     F_, h, w, C = 2, 4, 6, 64
     x = rnd(F_ * h * w, C, seed=42)
@@ -420,7 +420,7 @@ def test_im2col3x3_is_an_exact_gather(ops, ref):
     # and it is the convolution: im2col @ W^T == conv2d
     wt = rnd(8, C, 3, 3, seed=43, scale=0.1)
     conv = torch.nn.functional.conv2d(x.view(F_, h, w, C).permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1).reshape(-1, 8)
-    assert rel_l2(got.float().cpu() @ wt.reshape(8, -1).t(), conv) < 1e-5
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float().cpu() @ wt.reshape(8, -1).t(), conv), 1e-5)
 
 
 

@@ -36,7 +36,7 @@ def _run_hip(case, **over):
     return col, eng
 
 
-@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22"])
+@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22", "case_camtok"])
 def test_hip_joint_forward_matches_reference_golden(case_name, request, parity):
     case = request.getfixturevalue(case_name)
     col, _ = _run_hip(case)

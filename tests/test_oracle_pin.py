@@ -6,7 +6,7 @@ from conftest import rel_l2
 from oracle import fw_oracle
 
 
-@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22"])
+@pytest.mark.parametrize("case_name", ["case_l2", "case_l3", "case_w22", "case_camtok"])
 def test_oracle_matches_reference_golden(case_name, request):
     case = request.getfixturevalue(case_name)
     ins = case.inputs
@@ -14,7 +14,8 @@ def test_oracle_matches_reference_golden(case_name, request):
     out = fw_oracle.joint_forward(case.weights, case.cfg, ins["x"], ins["timestep"], ins["context"],
                                   ins["clip_feature"], ins["y"], ins["plucker_fea"], ins["plucker_context_lens"],
                                   uncond=case.uncond, collect=col,
-                                  control_camera_latents_input=ins.get("control_camera_latents_input"))
+                                  control_camera_latents_input=ins.get("control_camera_latents_input"),
+                                  camera_token=ins["camera_token"] if case.golden["meta"].get("camera_token") else None)
     col["noise_pred"] = out
     for k in ("x_after_pcb", "x_final", "tokens_final", "noise_pred"):
         err = rel_l2(col[k], case.golden[k])

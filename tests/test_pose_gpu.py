@@ -54,12 +54,12 @@ def test_patch_gather_without_padding_is_exact(ops, ref):
 
 
 @pytest.mark.parametrize("frames,hw,C,relu", [(5, 24, 384, False), (3, 7, 768, True), (1, 1000, 128, True)])
-def test_group_norm_rows(ops, ref, frames, hw, C, relu):
+def test_group_norm_rows(ops, ref, frames, hw, C, relu, parity, request):
     x = rnd(frames * hw, C, seed=3, scale=2.0) + 0.5
     w, b = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
     want = ref.group_norm_rows(x, frames, 2, w, b, relu=relu)
     got = ops.group_norm_rows(x.to(torch.bfloat16).cuda(), frames, 2, w.cuda(), b.cuda(), relu=relu)
-    assert rel_l2(got.float(), want) < 4e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
 @pytest.mark.parametrize("frames", [1, 2, 5, 8, 9])
@@ -71,10 +71,10 @@ def test_time_avg_pool(ops, ref, frames):
     assert fg == fw and got.shape == want.shape and rel_l2(got.float(), want) < 4e-3
 
 
-def test_activation(ops, ref):
+def test_activation(ops, ref, parity, request):
     x = rnd(77, 128, seed=7, scale=2.0)
     for act in ("gelu_erf", "relu", "silu"):
-        assert rel_l2(ops.activation(x.to(torch.bfloat16).cuda(), act).float(), ref.activation(x, act)) < 4e-3
+        parity.check(f"op/{request.node.name}/0", rel_l2(ops.activation(x.to(torch.bfloat16).cuda(), act).float(), ref.activation(x, act)), 4e-3)
 
 
 def test_pose_encoder_matches_reference_golden(pose_case, ops):

@@ -42,7 +42,7 @@ def test_upsampled_gather_is_exact(ops, ref, T, H, W, C, kt):
     assert got.shape == (T * 4 * H * W, kt * 9 * C) and torch.equal(got.float().cpu(), want)
 
 
-def test_upsampled_gather_then_gemm_is_upsample_plus_conv(ops):
+def test_upsampled_gather_then_gemm_is_upsample_plus_conv(ops, parity, request):
     """= nn.Upsample(scale_factor=2, mode='nearest-exact') followed by Conv2d 3x3 (Resample, wan_video_vae.py:92-99)."""
     import torch.nn.functional as F
     T, H, W, C, N = 2, 5, 7, 64, 128
@@ -51,7 +51,7 @@ def test_upsampled_gather_then_gemm_is_upsample_plus_conv(ops):
     want = F.conv2d(img, w, b, padding=1).permute(0, 2, 3, 1).reshape(T * 4 * H * W, N)
     lin = ops.pack_linear(w.permute(0, 2, 3, 1).reshape(N, 9 * C), b)
     got = ops.linear(ops.im2col(x.to(torch.bfloat16).cuda(), T, H, W, 1, 3, 3, up=2), lin, out_f32=True)
-    assert rel_l2(got, want) < 1e-3
+    parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-3)
 
 
 def test_bare_channel_rms_norm_and_row_softmax(ops, ref):

@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""tests/golden/parity_bounds_gpu.json = 1.5 x the errors measured on MI355X (profiles/rNN/parity.json, written by the GPU test
+session through conftest.ParityLog).  Usage: tools/make_parity_bounds.py profiles/r02/parity.json"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1]
+rows = json.load(open(src))
+bounds = {}
+for name, row in rows.items():
+    if isinstance(row, dict) and "measured" in row:
+        # 1.5 x measured; a floor keeps exact (0.0) or near-exact comparisons from becoming `< 0`
+        bounds[name] = max(1.5 * row["measured"], 1e-7)
+out = {"source": os.path.relpath(src, ROOT), "rule": "bound = max(1.5 * measured, 1e-7); enforced = min(test's physical bound, this)",
+       "bounds": dict(sorted(bounds.items()))}
+path = os.path.join(ROOT, "tests", "golden", "parity_bounds_gpu.json")
+with open(path, "w") as f:
+    json.dump(out, f, indent=1)
+print(f"{len(bounds)} bounds -> {path}")
