@@ -189,7 +189,17 @@ class HipOps:
         _check(self.lib.fw_set_option(self.OPTS[name], int(value)), "fw_set_option")
 
     def _stream(self):
+        # a kernel launched on another device's stream is undefined behaviour: one process drives ONE GPU through this object
+        if self.device.index is not None and torch.cuda.current_device() != self.device.index:
+            raise RuntimeError(f"HipOps bound to {self.device} but the current HIP device is {torch.cuda.current_device()}: "
+                               "call torch.cuda.set_device(...) (one process per GPU)")
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _check_dev(self, *tensors):
+        """Raw data_ptr() values cross the C ABI: a host tensor or one on another GPU must fail HERE, as a Python error."""
+        for t in tensors:
+            if t is not None and (not t.is_cuda or (self.device.index is not None and t.device.index != self.device.index)):
+                raise RuntimeError(f"tensor on {t.device} passed to HipOps bound to {self.device}")
 
     def empty(self, *shape, dtype=None):
         return torch.empty(*shape, dtype=dtype or self.act_dtype, device=self.device)
@@ -214,6 +224,7 @@ class HipOps:
 
     # ---- GEMM -------------------------------------------------------------------------------------------------
     def linear(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
+        self._check_dev(x if not isinstance(x, tuple) else x[0], res, out, g1, g0)
         if lin.fp8:
             return self._linear_fp8(x, lin, act, g1, g0, res, out_f32, out)
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1, (x.dtype, x.shape, x.stride())
@@ -244,6 +255,7 @@ class HipOps:
     # ---- norms ------------------------------------------------------------------------------------------------
     def layernorm(self, x, w=None, b=None, scale=None, shift=None, eps=1e-6, out=None):
         assert x.dim() == 2 and x.stride(1) == 1
+        self._check_dev(x, w, b, scale, shift, out)
         rows, C = x.shape
         if out is None:
             out = torch.empty(rows, C, dtype=torch.bfloat16, device=self.device)
@@ -256,6 +268,7 @@ class HipOps:
         """In place on x [rows, heads*hd] (may be a column slice of a wider buffer).  out_scale: multiplied in before the
         single bf16 rounding (the engine folds softmax_scale*log2(e) into q: see attention(q_prescaled=True))."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == heads * hd
+        self._check_dev(x, norm_w, norm_b, table)
         tab_rows = 0 if table is None else table.shape[0]
         if table is not None:
             assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1:] == (hd // 2, 2)
@@ -285,6 +298,7 @@ class HipOps:
         """softmax(q k^T / sqrt(hd)) v per (batch, head); q [batch*Lq, heads*hd], k/v [batch*Lk, heads*hd].
         q_prescaled: q already carries q_scale(hd) (scores are then used directly in the log2 domain)."""
         assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and q.stride(1) == 1 and k.stride(1) == 1
+        self._check_dev(q, k, v, out)
         Lq = q.shape[0] // batch
         Lk = k.shape[0] // batch
         vt, lk2 = v_prepared if v_prepared is not None else self.prepare_v(v, heads, hd, batch)
@@ -319,6 +333,7 @@ class HipOps:
 
     def patchify(self, x, y, kpad):
         """x [1,Cx,F,H2,W2], y [1,Cy,F,H2,W2] or None -> bf16 [L, kpad]."""
+        self._check_dev(x, y)
         x = x.contiguous()
         if x.dtype not in (torch.bfloat16, torch.float32):
             x = x.float()
@@ -350,6 +365,7 @@ class HipOps:
 
     def control_patchify(self, ctl):
         """ctl [1, C, F, 16h, 16w] (bf16/f32) -> bf16 [L, C*256]: PixelUnshuffle(8) + k2s2 patch gather of the Wan2.2 control adapter."""
+        self._check_dev(ctl)
         ctl = ctl.contiguous()
         if ctl.dtype not in (torch.bfloat16, torch.float32):
             ctl = ctl.float()
@@ -397,6 +413,7 @@ class HipOps:
     # ---- camera pose encoder ---------------------------------------------------------------------------
     def pixel_unshuffle_rows(self, x, r):
         assert x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32), (x.shape, x.dtype)
+        self._check_dev(x)
         Fr, H, W, C = x.shape
         out = torch.empty(Fr * (H // r) * (W // r), C * r * r, dtype=torch.bfloat16, device=self.device)
         _check(self.lib.fw_pixel_unshuffle(x.data_ptr(), _dt(x), out.data_ptr(), out.stride(0), Fr, H, W, C, r, self._stream()),

@@ -59,22 +59,43 @@ def heads_config_from_model(vggt):
         point_out=pts.scratch.output_conv2[2].out_channels)
 
 
-def install(model, ops=None, device=None, cache_step_invariants=True):
+def _weight_signature(params):
+    """(storage address, in-place version) of a spread of parameters: cheap evidence that the live module tree still holds the
+    tensors that were packed (load_state_dict / LoRA merge / .to() after install() change one or the other)."""
+    names = sorted(params)
+    pick = names[:: max(1, len(names) // 24)]
+    return tuple((n, params[n].data_ptr(), params[n]._version) for n in pick)
+
+
+def install(model, ops=None, device=None, cache_step_invariants=True, precision="bf16"):
     """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
     tests may inject another op set to exercise this boundary on CPU.  `cache_step_invariants`: keep the context embeddings,
     the per-block cross-attention K/V and the camera adapter's Pluecker term across the calls of a generation (the caller
-    passes the same tensors 100 times; results are bit-identical)."""
+    passes the same tensors 100 times; results are bit-identical).  `precision`: "bf16", or "fp8" = the
+    DiT blocks' linears through the reference's fp8 linear.
+
+    The weights are SNAPSHOT at install time into packed copies (36 GB for the 14B model, next to the reference's own): call
+    install() after checkpoint loading / LoRA merging / .to(dtype).  A later change of the live parameters is detected at the
+    next joint_forward (RuntimeError: install again) instead of being silently ignored; installing again drops the previous
+    engine and its caches first."""
+    if hasattr(model, "_fw_engine"):
+        model._fw_engine.invariants.clear()
+        uninstall(model)
     if ops is None:
         from .hip_ops import HipOps
         ops = HipOps(device or "cuda")
     cfg = config_from_model(model)
     params = dict(model.named_parameters())
     engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
-                          cache_step_invariants=cache_step_invariants)
+                          cache_step_invariants=cache_step_invariants, precision=precision)
+    signature = _weight_signature(params)
 
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
                       camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,
                       return_prediction=False, control_camera_latents_input=None, **kwargs):
+        if _weight_signature(dict(self.named_parameters())) != signature:
+            raise RuntimeError("the model's parameters changed after fantasy_world_amd.install() (load_state_dict, LoRA merge, "
+                               ".to()): the engine runs on a packed snapshot -- call install(model) again")
         out, outputs = engine.joint_forward(x, timestep, context, clip_feature=clip_feature, y=y,
                                             plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
                                             uncond=uncond, return_prediction=return_prediction,
@@ -153,6 +174,7 @@ def uninstall(model):
     if hasattr(model, "_fw_reference_joint_forward"):
         model.joint_forward = model._fw_reference_joint_forward
         del model._fw_reference_joint_forward
+        model._fw_engine.invariants.clear()
         del model._fw_engine
     cam = getattr(model, "camera_condition", None)
     if cam is not None and hasattr(cam, "_fw_reference_get_pose_fea"):

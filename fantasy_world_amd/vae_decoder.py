@@ -37,6 +37,7 @@ class VaeDecoder(ConvNetBase):
         self.default_scale = (mean, 1.0 / std)
         self._w2, self._b2 = w2, g("conv2.bias").float().cpu()
         self._conv2_cache = {}
+        self._conv2_ident = None
         d = "decoder."
         self.conv1 = self._conv(sub(d), "conv1")
         self.mid = [self._res(sub(d + "middle.0."), dims[0], dims[0]), self._attn(sub(d + "middle.1."), dims[0]),
@@ -74,12 +75,20 @@ class VaeDecoder(ConvNetBase):
 
     def _conv2(self, scale):
         """conv2 with z / scale[1] + scale[0] folded in; cached per scale (the reference passes [mean, 1/std])."""
-        mean, inv = (torch.as_tensor(s).float().reshape(-1).cpu() for s in scale)
+        # identity cache first: the reference hands the same two objects to every tile (wan_video_vae.py:643-692), so the host
+        # sync of .tolist() is paid once per generation, not per tile
+        ident = tuple((id(s), getattr(s, "_version", 0)) for s in scale)
+        if self._conv2_ident is not None and self._conv2_ident[0] == ident:
+            return self._conv2_ident[1]
+        # per-channel tensors or plain scalars (VideoVAE_.decode accepts both, wan_video_vae.py:556-561): expand to z_dim
+        mean, inv = (torch.as_tensor(s).float().reshape(-1).cpu().expand(self.z_dim).contiguous()
+                     if torch.as_tensor(s).numel() == 1 else torch.as_tensor(s).float().reshape(-1).cpu() for s in scale)
         key = (tuple(mean.tolist()), tuple(inv.tolist()))
         if key not in self._conv2_cache:
             w = self._w2 / inv[None, :]
             b = self._w2 @ mean + self._b2
             self._conv2_cache = {key: self._pack(w, b, _cpad(self.z_dim), _cpad(self.z_dim))}
+        self._conv2_ident = (ident, self._conv2_cache[key], tuple(scale))      # keeps the scale objects alive: ids stay unique
         return self._conv2_cache[key]
 
     # ------------------------------------------------------------------------------------------------ blocks

@@ -146,6 +146,12 @@ def test_vae_decoder_host_logic_matches_reference_golden(vae_case):
     want = c.golden["video"]
     got = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps()).decode(c.latents)
     assert got.shape == want.shape and rel_l2(got, want) < 1e-5
+    # scalar scale (VideoVAE_.decode's non-tensor branch): same as the per-channel tensors it stands for
+    dec = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps())
+    import torch
+    a = dec.decode(c.latents, [0.25, 2.0])
+    b = dec.decode(c.latents, [torch.full((16,), 0.25), torch.full((16,), 2.0)])
+    assert rel_l2(a, b) < 1e-6
     tiny = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps(), max_col_bytes=1).decode(c.latents)
     assert rel_l2(tiny, got) < 1e-5
     emu = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps(emulate_bf16=True)).decode(c.latents)
