@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=40, help="debug only: anything but 40 is not a BASELINE workload")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16")
     ap.add_argument("--cache-invariants", action="store_true")
+    ap.add_argument("--merge-cfg", action="store_true", help="N = 1: the two CFG forwards of a step as ONE pass over 2L rows")
     ap.add_argument("--experts", type=int, default=None, help="wan22: resident experts (default 2; 1 = high-noise only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="bound on the CPU baseline sample")
@@ -194,8 +195,9 @@ def main():
     def one_step(step_id, latents):
         if n_experts == 2:
             return denoise_step_dual(engines[0], engines[1], boundary, sched, step_id, latents, ins["context"],
-                                     ins["context_neg"], cond, topo=topo)[0]
-        return denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo)[0]
+                                     ins["context_neg"], cond, topo=topo, merge_cfg=args.merge_cfg)[0]
+        return denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo,
+                            merge_cfg=args.merge_cfg)[0]
 
     def barrier():
         if world > 1:
@@ -296,6 +298,7 @@ def main():
         "dtype": "fp8_e4m3 linears (fp32 accumulate), bf16 attention" if args.precision == "fp8" else "bf16", "data": "synthetic",
         "config": {"workload": workload, "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,
                    "parallelism": topo.describe(), "step_invariant_cache": bool(args.cache_invariants),
+                   "cfg_merged_in_one_pass": bool(args.merge_cfg and world == 1),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
         "roofline": {"bound": "mfma", "kernel": "attention_sp_kernel<128, 1> (DiT self-attention, one launch per block"

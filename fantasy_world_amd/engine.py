@@ -110,6 +110,7 @@ class FusionEngine:
         self.invariants = _InvariantCache(cache_step_invariants)
         self._tables = {}
         self._plucker_zero_cache = None
+        self._nb, self._ctx_sources, self._img_sources = 1, (), ()
         ops_ = ops
         g = lambda n: get(n).detach().to(torch.float32)
 
@@ -297,7 +298,7 @@ class FusionEngine:
         else:
             got = st.pend.wait()
             k, v = (st.qkv[:, D:2 * D], st.qkv[:, 2 * D:]) if got is None else (got[:, :D], got[:, D:])
-            st.pend = Ready(ops.attention(st.qkv[:, :D], k, v, H, hd, q_prescaled=True))
+            st.pend = Ready(ops.attention(st.qkv[:, :D], k, v, H, hd, batch=self._nb, q_prescaled=True))
         st.qkv = None
 
     def _dit_attn_end(self, st, ctx_txt, ctx_img, plucker):
@@ -332,16 +333,20 @@ class FusionEngine:
             ops.qk_prep(kvi[:, :D], H, hd, norm="rms_full", norm_w=blk.cnorm_k_img, eps=cfg.eps)
             return kvi
 
-        kv = self.invariants.get(("ckv", id(blk)), (ctx_txt,), text_kv)
-        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd, q_prescaled=True)
+        nb = self._nb
+        # cached on the identity of the tensors the CALLER passes (ctx_txt / ctx_img are derived objects, rebuilt per call when merged)
+        kv = self.invariants.get(("ckv", id(blk), nb), self._ctx_sources, text_kv)
+        oc = ops.attention(qc, kv[:, :D], kv[:, D:], H, hd, batch=nb, q_prescaled=True)
         if ctx_img is not None:
-            kvi = self.invariants.get(("ckv_img", id(blk)), (ctx_img,), image_kv)
-            ops.attention(qc, kvi[:, :D], kvi[:, D:], H, hd, out=oc, accumulate=True, q_prescaled=True)
+            kvi = self.invariants.get(("ckv_img", id(blk), nb), self._img_sources, image_kv)
+            ops.attention(qc, kvi[:, :D], kvi[:, D:], H, hd, batch=nb, out=oc, accumulate=True, q_prescaled=True)
         if blk.adapter and plucker is not None:
             # camera_control.py:109-127 ('adaln'): scale == 0 identically, so x <- x + shift
             t1 = ops.linear(oc, blk.a_g20, act="relu")
             pterm = self.invariants.get(("pterm", id(blk)), (plucker,), lambda: ops.linear(plucker, blk.a_g1))
-            if self.invariants.enabled:
+            if nb > 1:
+                pterm = pterm.repeat(nb, 1)                 # same camera for every merged sample (a fresh tensor)
+            elif self.invariants.enabled:
                 pterm = pterm.clone()                       # the next GEMM accumulates into its residual operand
             comb = ops.linear(t1, blk.a_g22, res=pterm, out=pterm)
             t2 = ops.linear(comb, blk.a_v0, act="relu")
@@ -461,9 +466,10 @@ class FusionEngine:
         else:
             p_qv1, p_kv2 = Ready(qv1), Ready(kv2)
         kv2_all = p_kv2.wait()
-        o1 = ops.attention(q_loc, kv2_all[:, :Bd], kv2_all[:, Bd:], Hb, hd, q_prescaled=True)      # softmax(q k^T) v2
+        nb = self._nb
+        o1 = ops.attention(q_loc, kv2_all[:, :Bd], kv2_all[:, Bd:], Hb, hd, batch=nb, q_prescaled=True)      # softmax(q k^T) v2
         qv1_all = p_qv1.wait()
-        o2 = ops.attention(k_loc, qv1_all[:, :Bd], qv1_all[:, Bd:], Hb, hd, q_prescaled=True)      # softmax(k q^T) v1
+        o2 = ops.attention(k_loc, qv1_all[:, :Bd], qv1_all[:, Bd:], Hb, hd, batch=nb, q_prescaled=True)      # softmax(k q^T) v1
         ops.linear(o1, bc.out1, g1=bc.gamma1, res=x, out_f32=True, out=x)
         ops.linear(o2, bc.out2, g1=bc.gamma2, res=tok, out_f32=True, out=tok)
 
@@ -495,7 +501,29 @@ class FusionEngine:
         it, the aggregator's output_list as a dict layer -> fp32 [1, S, P, 2*C] for the layers the heads read.
         `collect`: optional dict that receives intermediate tensors (tests).
         """
+        outs, pred = self._forward(x, timestep, [context], clip_feature, y, plucker_fea, plucker_context_lens, uncond,
+                                   return_prediction, camera_token, control_camera_latents_input, collect)
+        return outs[0], pred
+
+    @torch.no_grad()
+    def joint_forward_pair(self, x, timestep, context_pos, context_neg, clip_feature=None, y=None, plucker_fea=None,
+                           plucker_context_lens=None, uncond=False, return_prediction=False, camera_token=None,
+                           control_camera_latents_input=None):
+        """The two CFG forwards of a sampling step in ONE pass ("CFG batch-2 merge"; the reference runs them
+        one after the other, model_wan21.py:295-319, and diffsynth's own pipeline has the merged form,
+        diffsynth_wan22/pipelines/wan_video_new.py:1576-1580).  The positive and the negative pass share latents, timestep, image
+        / camera conditioning and differ ONLY in the text context, so every token-major op runs once on 2L rows (weights read
+        once, twice the rows per launch) and the attentions run with batch 2.  Same arithmetic per row as two joint_forward calls:
+        the results are bit-identical to them.  Returns (noise_pred_pos, noise_pred_neg, prediction of the positive pass)."""
+        assert self.shard is None, "merged CFG is the single-GPU form; with several GPUs the two passes go to two rank groups"
+        outs, pred = self._forward(x, timestep, [context_pos, context_neg], clip_feature, y, plucker_fea, plucker_context_lens,
+                                   uncond, return_prediction, camera_token, control_camera_latents_input, None)
+        return outs[0], outs[1], pred
+
+    def _forward(self, x, timestep, contexts, clip_feature, y, plucker_fea, plucker_context_lens, uncond, return_prediction,
+                 camera_token, control_camera_latents_input, collect):
         cfg, ops, sh = self.cfg, self.ops, self.shard
+        nb = self._nb = len(contexts)                          # samples stacked along the token rows (batch-major)
         assert x.shape[0] == 1, "the reference samples with batch 1 (model_wan21.py:254-258)"
         F, H2, W2 = x.shape[2:]
         h, w = H2 // 2, W2 // 2
@@ -516,8 +544,10 @@ class FusionEngine:
         e0 = ops.linear_f32(ev, self.vtimep, silu_in=True).view(6, cfg.vggt_dim)
 
         # ---- A2: context embeddings (wan_video_dit.py:388-392, 324-341) ----------------------------------------
-        ctx_txt = self.invariants.get("ctx_txt", (context,), lambda: ops.linear(
-            ops.linear(ops.to_act(context[0]), self.text0, act="gelu_tanh"), self.text2))
+        embs = [self.invariants.get("ctx_txt", (c,), lambda c=c: ops.linear(
+            ops.linear(ops.to_act(c[0]), self.text0, act="gelu_tanh"), self.text2)) for c in contexts]
+        ctx_txt = embs[0] if nb == 1 else torch.cat(embs, dim=0)                               # [nb * 512, D]
+        self._ctx_sources, self._img_sources = tuple(contexts), (clip_feature,)
         ctx_img = None
         if cfg.has_image_input:
             def image_ctx():
@@ -525,6 +555,8 @@ class FusionEngine:
                 ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
                 return ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
             ctx_img = self.invariants.get("ctx_img", (clip_feature,), image_ctx)
+            if nb > 1:
+                ctx_img = ctx_img.repeat(nb, 1)
 
         # ---- A3: patchify (Conv3d k=s=(1,2,2) as GEMM) ---------------------------------------------------------
         # Wan2.1 concatenates y when the DiT has image input (model_wan21.py:125-126), Wan2.2 whenever y is given (model_wan22.py:252-253)
@@ -542,6 +574,8 @@ class FusionEngine:
             patches = sh.take_dit_rows(patches)
             ycam = None if ycam is None else sh.take_dit_rows(ycam)
         xs = ops.linear(patches, self.patch, res=ycam, out_f32=True)                          # fp32 residual stream
+        if nb > 1:
+            xs = xs.repeat(nb, 1)             # the merged samples start from the same embedded latents; they diverge at the first cross-attention
 
         # ---- PCB: DiT blocks [0, start_index) ------------------------------------------------------------------
         for b in range(cfg.start_index):
@@ -560,7 +594,11 @@ class FusionEngine:
             S_loc = sh.my_frames
         else:
             S_loc = F
-        tok = ops.assemble_tokens(ptok, self._special_for(sh), S_loc, hw)                      # fp32 [S_loc*P, C]
+        if nb == 1:
+            tok = ops.assemble_tokens(ptok, self._special_for(sh), S_loc, hw)                  # fp32 [S_loc*P, C]
+        else:                                 # frame 0 of EVERY sample takes the first-frame camera / register tokens
+            Ln = ptok.shape[0] // nb
+            tok = torch.cat([ops.assemble_tokens(ptok[i * Ln:(i + 1) * Ln], self.special, S_loc, hw) for i in range(nb)], dim=0)
         if camera_token is not None:
             # CamTokenProjector (vggt/layers/block.py:276-297, aggregator.py:265-266): the learned camera token of every frame is
             # replaced by an MLP of 4 consecutive pose encodings (the sequence is padded with 3 copies of its first pose)
@@ -571,7 +609,7 @@ class FusionEngine:
             cam = ops.linear(ops.linear(ct, self.camtok0, act="gelu_erf"), self.camtok2, out_f32=True)     # fp32 [S, C]
             if sh is not None:
                 cam = cam[sh.first_frame:sh.first_frame + S_loc]
-            tok.view(S_loc, P, cfg.vggt_dim)[:, 0, :] = cam
+            tok.view(nb * S_loc, P, cfg.vggt_dim)[:, 0, :] = cam if nb == 1 else cam.repeat(nb, 1)
         if collect is not None:
             collect["tokens_in"] = tok.clone()
 
@@ -588,10 +626,10 @@ class FusionEngine:
             # (fusion/layer/block.py:59-74), so their stages are interleaved to hide the exchanges of one branch behind the
             # compute of the other (same arithmetic as the reference order: frame block, DiT partial, VGGT global partial).
             sd = self._dit_attn_begin(blk, xs, t_mod, tabs)                     # DiT q|k|v exchange in flight ...
-            e = self._vggt_attn(fb, tok, e0, tabs, batch=S_loc, frame_mode=True)   # ... behind the VGGT frame block
+            e = self._vggt_attn(fb, tok, e0, tabs, batch=nb * S_loc, frame_mode=True)   # ... behind the VGGT frame block
             self._vggt_mlp(fb, tok, e)
-            frame_out = tok.clone() if i in need else None
-            sg = self._vggt_attn_begin(gb, tok, e0, tabs, batch=1, frame_mode=False)   # VGGT exchange in flight ...
+            frame_out = tok[:S_loc * P].clone() if i in need else None                 # (merged: the positive sample's frames)
+            sg = self._vggt_attn_begin(gb, tok, e0, tabs, batch=nb, frame_mode=False)   # VGGT exchange in flight ...
             self._dit_attn_mid(sd)                                              # ... behind DiT self-attention
             self._vggt_attn_mid(sg)                                             # DiT output exchange behind VGGT attention
             mod = self._dit_attn_end(sd, ctx_txt, ctx_img, plucker)             # VGGT output exchange behind DiT cross-attn
@@ -604,7 +642,7 @@ class FusionEngine:
                 per_block("x", cfg.start_index + i, xs)
                 per_block("tok", i, tok)
             if i in need:
-                outputs[i] = torch.cat([frame_out.view(1, S_loc, P, -1), tok.view(1, S_loc, P, -1)], dim=-1)
+                outputs[i] = torch.cat([frame_out.view(1, S_loc, P, -1), tok[:S_loc * P].view(1, S_loc, P, -1)], dim=-1)
         if collect is not None:
             collect["x_final"] = xs.clone()
             collect["tokens_final"] = tok.clone()
@@ -614,15 +652,15 @@ class FusionEngine:
         hd_out = ops.linear(xn, self.head, out_f32=True)                                       # [L(local), 64]
         if sh is not None:
             hd_out = sh.all_gather_rows(hd_out, sh.dit_counts)
-        out = ops.unpatchify(hd_out, F, h, w, x.dtype)
+        outs = [ops.unpatchify(hd_out[i * L:(i + 1) * L], F, h, w, x.dtype) for i in range(nb)]
         if return_prediction:
             if sh is not None:
                 outputs = {k: sh.gather_frames(v) for k, v in outputs.items()}
             if self.heads_cfg is None:
-                return out, outputs
+                return outs, outputs
             # once per generation; with a sequence shard every rank holds all frames here and computes the same dict
-            return out, self.geometry_heads().predict(outputs, F, h, w, patch_start_idx=cfg.n_special)
-        return out, None
+            return outs, self.geometry_heads().predict(outputs, F, h, w, patch_start_idx=cfg.n_special)
+        return outs, None
 
     def geometry_heads(self):
         if self._heads is None:

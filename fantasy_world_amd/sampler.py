@@ -31,12 +31,15 @@ class FlowMatchScheduler:
 
 @torch.no_grad()
 def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cfg_scale=5.0, return_prediction=False,
-                 topo=None):
+                 topo=None, merge_cfg=False):
     """One sampling step = 2 joint_forward calls (CFG) + combine + scheduler update (M21:289-322).
     topo (fantasy_world_amd.parallel.Topology) with two CFG groups: this rank runs only its group's forward and the two
-    noise predictions are exchanged with one all-gather; the geometry prediction lives on the positive-prompt group."""
+    noise predictions are exchanged with one all-gather; the geometry prediction lives on the positive-prompt group.
+    merge_cfg (single GPU): both forwards in one pass over 2L rows (FusionEngine.joint_forward_pair; bit-identical results)."""
     t = scheduler.timesteps[step_id].reshape(1).to(device=latents.device, dtype=latents.dtype)
-    if topo is not None and topo.cfg_groups == 2:
+    if merge_cfg and (topo is None or topo.world == 1):
+        pos, neg, pred = engine.joint_forward_pair(latents, t, ctx_pos, ctx_neg, return_prediction=return_prediction, **cond)
+    elif topo is not None and topo.cfg_groups == 2:
         mine = ctx_pos if topo.cfg_rank == 0 else ctx_neg
         out, pred = engine.joint_forward(latents, t, mine, return_prediction=return_prediction and topo.cfg_rank == 0, **cond)
         pos, neg = topo.gather_cfg(out)
@@ -55,8 +58,8 @@ def select_expert(scheduler, step_id, engine_high, engine_low, timestep_boundary
 
 
 def denoise_step_dual(engine_high, engine_low, timestep_boundary, scheduler, step_id, latents, ctx_pos, ctx_neg, cond,
-                      cfg_scale=5.0, return_prediction=False, topo=None):
+                      cfg_scale=5.0, return_prediction=False, topo=None, merge_cfg=False):
     """One step of `generate_video_with_dual_models` (inference_wan22.py:227-277): pick the expert, then an ordinary step."""
     engine = select_expert(scheduler, step_id, engine_high, engine_low, timestep_boundary)
     return denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cfg_scale=cfg_scale,
-                        return_prediction=return_prediction, topo=topo)
+                        return_prediction=return_prediction, topo=topo, merge_cfg=merge_cfg)

@@ -222,3 +222,28 @@ def test_step_invariant_cache_is_exact_and_skips_work(case_l2):
     b, _ = cached.joint_forward(ins["x"], t2, ctx, **kw)
     ref_b, _ = plain.joint_forward(ins["x"], t2, ctx, **kw)
     assert torch.equal(a, want2) and torch.equal(b, ref_b) and not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case_name", ["case_l2", "case_w22"])
+def test_merged_cfg_pair_equals_two_forwards(case_name, request):
+    """SURVEY.md 8(f) item 2, CFG batch-2 merge: joint_forward_pair runs the positive and the negative pass as one forward over 2L
+    rows (attention batch 2); every op is row-wise or per (batch, head), so the two results equal the two separate forwards
+    exactly -- with and without the step-invariant cache, and through sampler.denoise_step(merge_cfg=True)."""
+    from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step
+    case = request.getfixturevalue(case_name)
+    ins = case.inputs
+    kw = forward_kwargs(case)
+    for cached in (False, True):
+        eng = FusionEngine(case.cfg, case.weights.__getitem__, TorchRefOps(), cache_step_invariants=cached)
+        for rep in range(2):                        # second round: served from the cache when it is on
+            pos, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+            neg, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context_neg"], **kw)
+            mp, mn, pred = eng.joint_forward_pair(ins["x"], ins["timestep"], ins["context"], ins["context_neg"], **kw)
+            assert pred is None and rel_l2(mp, pos) < 1e-6 and rel_l2(mn, neg) < 1e-6, (cached, rep)
+            assert rel_l2(pos, neg) > 1e-3          # the two prompts really differ
+    sched = FlowMatchScheduler()
+    sched.set_timesteps(50)
+    cond = {k: v for k, v in kw.items() if k != "uncond"}
+    a, _ = denoise_step(eng, sched, 3, ins["x"], ins["context"], ins["context_neg"], cond)
+    b, _ = denoise_step(eng, sched, 3, ins["x"], ins["context"], ins["context_neg"], cond, merge_cfg=True)
+    assert rel_l2(b, a) < 1e-6

@@ -138,6 +138,26 @@ def test_hip_fp8_engine_matches_fp8_oracle(case_l2, case_cfg1, parity):
         del eng
 
 
+def test_hip_merged_cfg_pair_equals_two_forwards(case_l2, case_cfg1):
+    """CFG batch-2 merge on the GPU (FusionEngine.joint_forward_pair): one pass over 2L rows, attention batch 2 -- every kernel
+    computes a row / a (batch, head, q-block) exactly as in the separate forwards, so the results are BIT-identical (small case
+    and BASELINE config 1, where the 256x256 GEMMs, multi-block attention and the frame-batched VGGT attention are in play)."""
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    ops = HipOps("cuda:0")
+    for case in (case_l2, case_cfg1):
+        eng = FusionEngine(case.cfg, case.weights.__getitem__, ops, cache_step_invariants=True)
+        d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
+        kw = forward_kwargs(case, "cuda")
+        pos, _ = eng.joint_forward(d["x"], d["timestep"], d["context"], **kw)
+        neg, _ = eng.joint_forward(d["x"], d["timestep"], d["context_neg"], **kw)
+        mp, mn, pred = eng.joint_forward_pair(d["x"], d["timestep"], d["context"], d["context_neg"], **kw)
+        torch.cuda.synchronize()
+        assert pred is None and torch.equal(mp, pos) and torch.equal(mn, neg), case.name
+        assert not torch.equal(pos, neg)
+        del eng
+
+
 def test_hip_denoise_step_matches_oracle(case_l2, parity):
     """A18 on the GPU: one sampling step (2 joint_forward + CFG combine + flow-match Euler update, M21:289-322) through
     sampler.denoise_step against the same step assembled from the CPU oracle's two forwards."""

@@ -41,6 +41,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sp", default="1,2,4,8")
     ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--host-cost", action="store_true",
+                    help="also run the SAME full-depth engine (same launch count, same Python path) on a tiny latent grid, where "
+                         "the GPU finishes every kernel in microseconds: that forward's wall time IS the host's enqueue cost "
+                         "(Python + ctypes + torch.empty per op) -- the number that decides whether a HIP graph would pay")
     args = ap.parse_args()
     dev = "cuda:0"
     ops = HipOps(dev)
@@ -65,6 +69,20 @@ def main():
         base = base or dt
         print(f"sp={n}: one forward (rank 0 shapes) {dt*1e3:8.1f} ms   compute-only speed-up vs sp=1: {base/dt:5.2f}x   "
               f"(x{2 if True else 1} CFG groups -> {2*n} GPUs: step = {dt*1e3:.0f} ms + comm)", flush=True)
+        if args.host_cost:
+            tiny = synth.make_inputs(cfg, 8, 8, 8, seed=1, device=dev, dtype=torch.bfloat16)      # 8 latent frames: >= 1 per rank
+            tc = dict(clip_feature=tiny["clip_feature"], y=tiny["y"], plucker_fea=tiny["plucker_fea"],
+                      plucker_context_lens=tiny["plucker_context_lens"])
+            for _ in range(2):
+                eng.joint_forward(tiny["x"], t, tiny["context"], **tc)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(5):
+                eng.joint_forward(tiny["x"], t, tiny["context"], **tc)
+            torch.cuda.synchronize()
+            th = (time.time() - t0) / 5
+            print(f"        host enqueue cost of one forward at sp={n} (tiny grid, launch-bound): {th*1e3:6.1f} ms = "
+                  f"{100*th/dt:4.1f} % of the full-size forward's {dt*1e3:.0f} ms", flush=True)
         del eng
         torch.cuda.empty_cache()
 
