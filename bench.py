@@ -13,8 +13,9 @@ positive + negative, return_prediction=False) + CFG combine + flow-match Euler u
 Other workloads (never the headline; `config.workload` names them):
     --model wan22 --height 720 --width 1280     BASELINE configs[3]: Wan2.2-Fun-A14B-Control-Camera, both experts resident,
                                                 expert chosen per step (inference_wan22.py:229-277)
-    --precision fp8                             BASELINE configs[4]'s arithmetic: the DiT / VGGT linears through the fp8 linear
+    --precision fp8                             BASELINE configs[4]'s arithmetic: the DiT blocks' linears through the fp8 linear
                                                 (diffsynth_wan22/vram_management/layers.py:115-151); `dtype` says "fp8_e4m3"
+    --merge-cfg                                 N = 1: both CFG passes of a step as one forward over 2L rows
     --cache-invariants                          step-invariant intermediates cached; off = the
                                                 reference's per-step work
 N > 1 (fantasy_world_amd/parallel.py): the two CFG forwards go to two rank groups, each group sequence-shards its forward (head
