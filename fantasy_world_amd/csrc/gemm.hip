@@ -256,7 +256,9 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
                                             int fi, int hi, int lane, int m0, int n0) {
     // Pass rb: the wave's 32 x 128 fp32 block goes through a private 16 KiB LDS region (raw accumulators in, row-contiguous
     // 16 B per lane out); bias / activation / per-column affine / residual are applied on the way out, where a lane owns 4
-    // fixed columns and whole 512-B (fp32) / 256-B (bf16) row segments are read and written.
+    // fixed columns and whole 512-B (fp32) / 256-B (bf16) row segments are read and written.  All 16 residual loads of a pass are
+    // issued BEFORE the LDS transpose (the fp32 stream's HBM latency is paid once per pass), and the next pass's loads before this
+    // pass's stores.
     char* reg = smem + wave * 16384;
     const int rl = lane >> 5;                  // row inside a 2-row read group
     const int c4 = (lane & 31) * 4;            // first of this lane's 4 columns
@@ -269,44 +271,76 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
         if (p.g0) g04 = *(const f32x4_t*)(p.g0 + gcol);
     }
     const int act = p.act;
+    auto run = [&](auto res_tag) __attribute__((always_inline)) {
+        constexpr int RES = decltype(res_tag)::value;          // FW_DT_NONE / FW_DT_BF16 / FW_DT_F32
+        // residual values of TWO passes at a time (32 loads = 32 KiB per wave, 128 KiB per CU in flight: with four waves per CU one
+        // pass alone leaves the HBM latency half exposed; the fragment / staging registers of the mainloop are dead here)
+        f32x4_t rv[2][16];
+        u32x2_t rw[2][16];
+        auto load_res = [&](auto rb_tag) __attribute__((always_inline)) {
+            constexpr int rb = decltype(rb_tag)::value;
+            if (RES == FW_DT_NONE) return;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row_l = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                *(float*)(reg + row_l * 512 + (nb * 32 + fi) * 4) = acc[rb][nb][r];
+            for (int it = 0; it < 16; ++it) {
+                const int row = m0 + wm * 128 + rb * 32 + it * 2 + rl;
+                const bool ok = row < p.M && col_ok;
+                if (RES == FW_DT_F32) {
+                    rv[rb & 1][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (ok) rv[rb & 1][it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+                } else {
+                    rw[rb & 1][it] = u32x2_t{0u, 0u};
+                    if (ok) rw[rb & 1][it] = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
+                }
             }
-#pragma unroll 2
-        for (int it = 0; it < 16; ++it) {
-            const int row_l = it * 2 + rl;
-            f32x4_t v = *(const f32x4_t*)(reg + row_l * 512 + c4 * 4);
-            const int row = m0 + wm * 128 + rb * 32 + row_l;
-            if (row < p.M && col_ok) {
+        };
+        auto pass = [&](auto rb_tag) __attribute__((always_inline)) {
+            constexpr int rb = decltype(rb_tag)::value;          // compile-time: acc[] must never be indexed dynamically
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    *(float*)(reg + row_l * 512 + (nb * 32 + fi) * 4) = acc[rb][nb][r];
+                }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row_l = it * 2 + rl;
+                f32x4_t v = *(const f32x4_t*)(reg + row_l * 512 + c4 * 4);
+                const int row = m0 + wm * 128 + rb * 32 + row_l;
                 v += bias4;
                 if (act != FW_ACT_NONE) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
                 }
                 v = v * g14 + g04;
-                if (p.res_dtype == FW_DT_F32) {
-                    const f32x4_t rv = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
-                    v += rv;
-                } else if (p.res_dtype == FW_DT_BF16) {
-                    const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
-                    v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
+                if (RES == FW_DT_F32) {
+                    v += rv[rb & 1][it];
+                } else if (RES == FW_DT_BF16) {
+                    v[0] += __uint_as_float(rw[rb & 1][it][0] << 16); v[1] += __uint_as_float(rw[rb & 1][it][0] & 0xffff0000u);
+                    v[2] += __uint_as_float(rw[rb & 1][it][1] << 16); v[3] += __uint_as_float(rw[rb & 1][it][1] & 0xffff0000u);
                 }
-                if (p.out_dtype == FW_DT_F32) {
-                    *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
-                } else {
-                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                if (row < p.M && col_ok) {
+                    if (p.out_dtype == FW_DT_F32) {
+                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                    } else {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                    }
                 }
             }
-        }
-    }
+        };
+        using R0 = std::integral_constant<int, 0>;
+        using R1 = std::integral_constant<int, 1>;
+        using R2 = std::integral_constant<int, 2>;
+        using R3 = std::integral_constant<int, 3>;
+        load_res(R0{}); load_res(R1{});
+        pass(R0{}); pass(R1{});
+        load_res(R2{}); load_res(R3{});
+        pass(R2{}); pass(R3{});
+    };
+    if (p.res_dtype == FW_DT_F32) run(std::integral_constant<int, FW_DT_F32>{});
+    else if (p.res_dtype == FW_DT_BF16) run(std::integral_constant<int, FW_DT_BF16>{});
+    else run(std::integral_constant<int, FW_DT_NONE>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------

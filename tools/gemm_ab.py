@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Interleaved A/B of the big-tile GEMM kernels (FW_GEMM_KERNEL values) on the DiT shapes: the variants alternate inside one
+process, several rounds each, and the MEDIAN per variant is reported -- box-to-box and minute-to-minute clock drift (+-3 %) is larger
+than the differences being measured, so sequential single runs cannot rank them."""
+import argparse
+import os
+import statistics
+import sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fantasy_world_amd.hip_ops import HipOps, Linear
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--kernels", default="4,5")
+ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--iters", type=int, default=6)
+ap.add_argument("--zeros", action="store_true", help="zero-filled operands: the same instruction stream at a fraction of the switching power (DVFS check)")
+args = ap.parse_args()
+kernels = [tuple(int(v) for v in (k.split(":") + ["0"])[:2]) for k in args.kernels.split(",")]
+ops = HipOps("cuda:0")
+g = torch.Generator(device="cuda").manual_seed(0)
+L = 32760
+for (M, N, K, tag, res) in [(L, 15360, 5120, "qkv", False), (L, 13824, 5120, "ffn0", False), (L, 5120, 5120, "o", False),
+                            (L, 5120, 5120, "o+res", True), (L, 5120, 13824, "ffn2+res", True)]:
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    lin = Linear(torch.randn(N, K, device="cuda", generator=g).to(torch.bfloat16) * K ** -0.5, torch.zeros(N, device="cuda"))
+    if args.zeros:
+        x.zero_()
+        lin.w.zero_()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    xs = torch.randn(M, N, device="cuda") if res else None
+    gate = torch.randn(N, device="cuda") if res else None
+    times = {k: [] for k in kernels}
+    for r in range(args.rounds):
+        for k in kernels:
+            ops.set_option("gemm_kernel", k[0])
+            ops.set_option("gemm_var", k[1])
+            fn = (lambda: ops.linear(x, lin, g1=gate, res=xs, out_f32=True, out=xs)) if res else (lambda: ops.linear(x, lin, out=out))
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            times[k].append(a.elapsed_time(b) / args.iters)
+    line = f"{tag:9s} M={M} N={N} K={K}: "
+    for k in kernels:
+        med = statistics.median(times[k])
+        line += f" kernel {k}: {med:.3f} ms = {2.0*M*N*K/med/1e9:7.1f} TF/s (min {min(times[k]):.3f})  |"
+    print(line, flush=True)
+ops.set_option("gemm_kernel", 4)
+ops.set_option("gemm_var", 0)
