@@ -51,6 +51,12 @@ __device__ __forceinline__ float fw_apply_act(float v, int act) {
     }
 }
 
+// Per-column affine of the GEMM epilogues (gate / LayerScale / modulation): ONE fused multiply-add, spelled out so that every GEMM
+// kernel rounds it the same way -- rows that fall into the 128x128 tail kernel in one call and into a 256x256 tile in another
+// (the merged CFG pass stacks two samples along the rows) must come out bit-identical.  Left to the compiler's contraction the
+// kernels disagreed in the last bit.
+__device__ __forceinline__ float fw_affine(float v, float g1, float g0) { return __builtin_fmaf(v, g1, g0); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 if (row < p.M && col_ok) {
                     float v = acc[rb][nb][r] + bias;
                     v = fw_apply_act(v, p.act);
-                    v = v * g1 + g0;
+                    v = fw_affine(v, g1, g0);
                     if (p.res_dtype == FW_DT_F32) v += ((const float*)p.res)[(int64_t)row * p.ldr + col];
                     else if (p.res_dtype == FW_DT_BF16) v += bf16_bits_to_f32(((const uint16_t*)p.res)[(int64_t)row * p.ldr + col]);
                     if (p.out_dtype == FW_DT_F32) ((float*)p.C)[(int64_t)row * p.ldc + col] = v;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[2 * q + rb2][nb][r] + bias2[nb];
                     v = fw_apply_act(v, p.act);
-                    v = v * g12[nb] + g02[nb];
+                    v = fw_affine(v, g12[nb], g02[nb]);
                     const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
                 }
@@ -312,7 +312,8 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
                 }
-                v = v * g14 + g04;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], g14[j], g04[j]);
                 if (RES == FW_DT_F32) {
                     v += rv[rb & 1][it];
                 } else if (RES == FW_DT_BF16) {

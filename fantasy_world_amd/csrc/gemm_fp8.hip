@@ -81,12 +81,14 @@ __device__ __forceinline__ void epilogue_fp8(const QArgs& p, char* smem, f32x16_
             const int row = m0 + grp * 128 + q * 64 + row_l;
             if (row < p.M && col_ok) {
                 const float s = p.scale_a[row];
-                v = v * s + bias4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], s, bias4[j]);
                 if (act != FW_ACT_NONE) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
                 }
-                v = v * g14 + g04;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], g14[j], g04[j]);
                 if (p.res_dtype == FW_DT_F32) {
                     v += *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
                 } else if (p.res_dtype == FW_DT_BF16) {
@@ -347,9 +349,9 @@ __global__ __launch_bounds__(256) void gemm_fp8_small_kernel(QArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (m >= p.M) continue;
-                float y = acc[a][b][r] * p.scale_a[m] + bv;
+                float y = fw_affine(acc[a][b][r], p.scale_a[m], bv);
                 y = fw_apply_act(y, p.act);
-                y = y * g1 + g0;
+                y = fw_affine(y, g1, g0);
                 if (p.res_dtype == FW_DT_F32) y += ((const float*)p.res)[(int64_t)m * p.ldr + n];
                 else if (p.res_dtype == FW_DT_BF16) y += bf16_bits_to_f32(((const uint16_t*)p.res)[(int64_t)m * p.ldr + n]);
                 if (p.out_dtype == FW_DT_F32) ((float*)p.C)[(int64_t)m * p.ldc + n] = y;

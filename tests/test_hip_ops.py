@@ -134,6 +134,28 @@ def test_gemm_big_tile_fused_epilogue(ops, ref, res_dtype, out_f32, kern, parity
     parity.check(f"op/gemm_big_epilogue/k{kern}/{res_dtype}", rel_l2(got.float(), want), 1e-3 if out_f32 else 4e-3)
 
 
+@pytest.mark.parametrize("N,K", [(1024, 1024), (1536, 2048)])
+@pytest.mark.parametrize("act", ["none", "gelu_tanh"])
+def test_gemm_rows_do_not_depend_on_their_tile(ops, N, K, act):
+    """A row's result must not depend on WHICH kernel computed it: M = 2 * 301 puts sample 0's last 45 rows in a 256-row tile and
+    sample 1's first 211 rows beside them, while the same rows computed alone fall into the 128x128 tail kernel (and vice versa).
+    With bias + activation + per-column affine + fp32 residual the stacked call equals the two separate calls BIT FOR BIT -- the
+    property the merged CFG pass (two samples stacked along the rows) rests on.  (K = 1024: four-wave kernel; 2048: ping-pong.)"""
+    M = 301
+    x = bf(rnd(2 * M, K, seed=41)).cuda()
+    w, b = rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43, scale=0.1)
+    g1, g0 = rnd(N, seed=44).cuda(), rnd(N, seed=45).cuda()
+    res = torch.randn(2 * M, N, generator=torch.Generator().manual_seed(46)).cuda()
+    lin = ops.pack_linear(w, b)
+    kw = dict(g1=g1, g0=g0, out_f32=True)
+    if act != "none":
+        kw["act"] = act
+    both = ops.linear(x, lin, res=res.clone(), **kw)
+    for i in range(2):
+        alone = ops.linear(x[i * M:(i + 1) * M].contiguous(), lin, res=res[i * M:(i + 1) * M].clone(), **kw)
+        assert torch.equal(both[i * M:(i + 1) * M], alone), f"sample {i}"
+
+
 def test_gemm_rejects_bad_k(ops):
     x = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
     from fantasy_world_amd.hip_ops import Linear
