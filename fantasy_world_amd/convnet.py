@@ -1,5 +1,7 @@
 """Shared plumbing of the convolutional tails (geometry heads, VAE decoder): channels-last feature maps [frames*H*W, C] with C
-padded to a multiple of 64, convolution weights flattened tap-major to match `fw_im2col`, every convolution = gather + GEMM."""
+padded to a multiple of 64, convolution weights flattened tap-major; a k x k (x k) convolution is ONE implicit-GEMM launch
+(`fw_conv_gemm_bf16`: the tap gather is the LDS-DMA source address of the GEMM's A tile); `implicit_conv = False` on an instance
+selects the older gather (`fw_im2col`) + GEMM pair, which computes the same bits and is kept as the A/B and test reference."""
 import torch
 
 
@@ -70,6 +72,10 @@ class ConvNetBase:
         assert K == lin.K, (K, lin.K)
         if kt == 1 and kh == 1 and kw == 1 and up == 1:
             return ops.linear(x, lin, act=act, res=res, out_f32=out_f32)
+        if C % 64 == 0 and not relu_in and getattr(self, "implicit_conv", True):
+            # one implicit-GEMM launch per <= 255 frames: the gathered matrix is never written (fw_conv_gemm_bf16)
+            if T <= 255 and (Ho - 1) * sh <= 4095 and (Wo - 1) * sw <= 4095:
+                return ops.conv_gemm(x, T, H, W, lin, kt, kh, kw, sh=sh, sw=sw, up=up, act=act, res=res, out_f32=out_f32)
         step = max(1, int(self.max_col_bytes // (rpf * K * 2)))
         out = ops.empty(T * rpf, lin.N, dtype=torch.float32 if out_f32 else ops.act_dtype)
         for t0 in range(0, T, step):

@@ -22,6 +22,18 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
 constexpr int GROUP_M = 8;
 
+// Implicit-GEMM convolution (fw_conv_gemm_bf16): the A operand is never materialised.  A is the channels-last feature map
+// x [T*H*W][C] (lda = its row stride), GEMM row r = output pixel (t, yo, xo), GEMM column k = tap * C + c with tap = (dt*kh + dy)*kw
+// + dx.  C is a multiple of the k-slab (64), so a slab lies inside ONE tap: the LDS-DMA source of a tile row is just another row of x
+// (or 128 B of zeros outside the volume) -- the gather costs an address computation per DMA piece and no memory traffic.
+struct ConvGeom {
+    int T, H, W, Ho, Wo;                 // stored map, output map
+    int kt, kh, kw, sh, sw, ph, pw;      // taps, spatial stride / padding (time: causal, kt - 1 frames of history)
+    int ups;                             // log2 of the nearest-neighbour up-sampling the convolution sees (0 or 1)
+    int t0;                              // first output frame
+    int cpt;                             // k-slabs per tap = C / 64
+};
+
 struct GemmArgs {
     const uint16_t* A; int64_t lda;
     const uint16_t* W; int64_t ldw;
@@ -30,8 +42,48 @@ struct GemmArgs {
     const float* bias; int act; const float* g1; const float* g0;
     const void* res; int64_t ldr; int res_dtype;
     int tiles_m, tiles_n;
+    ConvGeom cv;                         // read by the CONV instantiations only
 };
 
+__device__ __attribute__((aligned(128))) uint16_t g_conv_zero[64];     // the 128-B row every out-of-volume tap reads
+
+// (absolute frame | yo * sh | xo * sw) of output row r, 8 + 12 + 12 bits (the launcher checks the ranges)
+__device__ __forceinline__ unsigned conv_row_pack(const ConvGeom& g, int r) {
+    const int hw = g.Ho * g.Wo;
+    const int tt = r / hw, rem = r - tt * hw;
+    const int yo = rem / g.Wo, xo = rem - yo * g.Wo;
+    return ((unsigned)(g.t0 + tt) << 24) | ((unsigned)(yo * g.sh) << 12) | (unsigned)(xo * g.sw);
+}
+
+// Position of a k-slab in the tap walk (wave-uniform: lives in SGPRs); slabs are visited in order, so no division is needed.
+struct ConvTap { int cc, dx, dy, dt; };
+__device__ __forceinline__ void conv_tap_next(const ConvGeom& g, ConvTap& t) {
+    // selects, not branches: this runs inside the MFMA bursts of the ping-pong kernel, whose phases must stay single basic blocks
+    const int cc = t.cc + 1;
+    const int wc = cc == g.cpt;
+    t.cc = wc ? 0 : cc;
+    const int dx = t.dx + wc;
+    const int wx = dx == g.kw;
+    t.dx = wx ? 0 : dx;
+    const int dy = t.dy + wx;
+    const int wy = dy == g.kh;
+    t.dy = wy ? 0 : dy;
+    t.dt += wy;
+}
+
+// Source of this lane's 16 bytes of a DMA piece: row `pack` of the output, slab position `t`, byte offset of the (swizzled) chunk
+__device__ __forceinline__ const char* conv_src(const GemmArgs& p, unsigned pack, const ConvTap& t, int chunk_bytes) {
+    const ConvGeom& g = p.cv;
+    const int ti = (int)(pack >> 24) + t.dt - (g.kt - 1);
+    const int yi = (int)((pack >> 12) & 0xfffu) + t.dy - g.ph;
+    const int xi = (int)(pack & 0xfffu) + t.dx - g.pw;
+    const bool ok = (unsigned)ti < (unsigned)g.T && (unsigned)yi < (unsigned)(g.H << g.ups) && (unsigned)xi < (unsigned)(g.W << g.ups);
+    const int64_t row = ((int64_t)ti * g.H + (yi >> g.ups)) * g.W + (xi >> g.ups);
+    const char* src = (const char*)p.A + (row * p.lda + t.cc * 64) * 2 + chunk_bytes;
+    return ok ? src : (const char*)g_conv_zero + chunk_bytes;
+}
+
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
@@ -66,6 +118,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     // 8*pc .. 8*pc+7; lane -> (row = 8*pc + lane/8, physical chunk = lane%8); logical chunk = phys ^ ((row>>1)&7).
     const uint16_t* ag[4];
     const uint16_t* wg_[4];
+    unsigned apack[4];                     // CONV: the output pixel of each of this lane's 4 tile rows
+    int achunk[4];
+    ConvTap tap = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pc = wave * 4 + i;
@@ -73,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const int ar = min(m0 + row, p.M - 1);
         const int wr = min(n0 + row, p.N - 1);
-        ag[i] = p.A + (int64_t)ar * p.lda + chunk * 8;
+        if (CONV) { apack[i] = conv_row_pack(p.cv, ar); achunk[i] = chunk * 16; }
+        else ag[i] = p.A + (int64_t)ar * p.lda + chunk * 8;
         wg_[i] = p.W + (int64_t)wr * p.ldw + chunk * 8;
     }
 
@@ -83,11 +139,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = wave * 4 + i;
-            FW_GLDS16(ag[i], a_lds + pc * 1024);
+            if (CONV) {
+                FW_GLDS16(conv_src(p, apack[i], tap, achunk[i]), a_lds + pc * 1024);
+            } else {
+                FW_GLDS16(ag[i], a_lds + pc * 1024);
+                ag[i] += BK;
+            }
             FW_GLDS16(wg_[i], b_lds + pc * 1024);
-            ag[i] += BK;
             wg_[i] += BK;
         }
+        if (CONV) conv_tap_next(p.cv, tap);
     };
 
     // ---- fragment read offsets -------------------------------------------------------------------------
@@ -363,10 +424,14 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
 //     group B: end of LOAD1(t): vmcnt(2) -> own B/A0(t+1) landed;   end of MFMA1(t): vmcnt(6) -> own A1(t+1) landed
 //   each ahead of the barrier that precedes the first read of that unit by any wave.
 // ---------------------------------------------------------------------------------------------------------------
-#define FW_PP_A(S, KT, U, I) FW_GLDS16(abase + (size_t)(KT) * (BK * 2) + aoff[U][I], smem + (S) * STAGE2 + ((U) * 16 + wave * 2 + (I)) * 1024)
+// (CONV: the A source of slab KT comes from the tap walk -- `tap6` / `tap2` are the positions of the next slab the 6-piece and the
+//  2-piece issue streams will request; both streams visit the slabs in order, each advances its own position after issuing)
+#define FW_PP_A(S, KT, U, I, TAP) FW_GLDS16(CONV ? conv_src(p, aoff[U][I], TAP, achunk[U][I]) : abase + (size_t)(KT) * (BK * 2) + aoff[U][I], \
+                                            smem + (S) * STAGE2 + ((U) * 16 + wave * 2 + (I)) * 1024)
 #define FW_PP_W(S, KT, U, I) FW_GLDS16(wbase + (size_t)(KT) * (BK * 2) + woff[U][I], smem + (S) * STAGE2 + TM * BK * 2 + ((U) * 16 + wave * 2 + (I)) * 1024)
-#define FW_PP_ISSUE6(S, KT) do { FW_PP_W(S, KT, 0, 0); FW_PP_W(S, KT, 0, 1); FW_PP_W(S, KT, 1, 0); FW_PP_W(S, KT, 1, 1); FW_PP_A(S, KT, 0, 0); FW_PP_A(S, KT, 0, 1); } while (0)
-#define FW_PP_ISSUE2(S, KT) do { FW_PP_A(S, KT, 1, 0); FW_PP_A(S, KT, 1, 1); } while (0)
+#define FW_PP_ISSUE6(S, KT) do { FW_PP_W(S, KT, 0, 0); FW_PP_W(S, KT, 0, 1); FW_PP_W(S, KT, 1, 0); FW_PP_W(S, KT, 1, 1); FW_PP_A(S, KT, 0, 0, tap6); FW_PP_A(S, KT, 0, 1, tap6); \
+                                 if (CONV) conv_tap_next(p.cv, tap6); } while (0)
+#define FW_PP_ISSUE2(S, KT) do { FW_PP_A(S, KT, 1, 0, tap2); FW_PP_A(S, KT, 1, 1, tap2); if (CONV) conv_tap_next(p.cv, tap2); } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Round 2 (against round 1's gemm_bf16_pp_kernel, same slot table): what changed was read off the ISA:
@@ -381,7 +446,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
 // ---------------------------------------------------------------------------------------------------------------
 __device__ unsigned long long g_gemm_ts[2 * 64];     // TIMING build: [group][slab 0..3][phase 0..3][start | end of work]
 
-template <bool TS>
+template <bool TS, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
 
@@ -413,14 +478,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
 
     const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
     const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
-    unsigned aoff[2][2], woff[2][2];       // [unit][piece]
+    unsigned aoff[2][2], woff[2][2];       // [unit][piece]; CONV: aoff holds the packed output pixel of the row instead
+    int achunk[2][2];
+    ConvTap tap6 = {0, 0, 0, 0}, tap2 = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = u * 128 + (wave * 2 + i) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            aoff[u][i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+            if (CONV) { aoff[u][i] = conv_row_pack(p.cv, min(m0 + row, p.M - 1)); achunk[u][i] = chunk * 16; }
+            else aoff[u][i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
             woff[u][i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
         }
 
@@ -771,7 +839,7 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
             t.res = res ? (const char*)res + (size_t)Mfull * ldr * rbytes : nullptr;
             t.M = tail;
             t.tiles_m = 1; t.tiles_n = (N + BN - 1) / BN;
-            hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)t.tiles_n), dim3(256), 0, (hipStream_t)stream, t);
+            hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3((unsigned)t.tiles_n), dim3(256), 0, (hipStream_t)stream, t);
             return (int)hipGetLastError();
         }
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
@@ -783,16 +851,66 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         if (kern == 5 || (kern == 4 && K <= 1280)) {
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
-            hipLaunchKernelGGL(gemm_bf16_pp2_kernel<true>, dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
         } else {
-            hipLaunchKernelGGL(gemm_bf16_pp2_kernel<false>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<false, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);
         }
         return (int)hipGetLastError();
     }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, int H, int W, int kt, int kh, int kw,
+                                 int sh, int sw, int ph, int pw, int up, int t0, int nt,
+                                 const uint16_t* Wt, int64_t ldw, void* Cout, int64_t ldc, int out_dtype, int N,
+                                 const float* bias, int act, const float* g1, const float* g0,
+                                 const void* res, int64_t ldr, int res_dtype, void* stream) {
+    if (N <= 0 || nt <= 0) return 0;
+    if (C <= 0 || (C % BK) || (ldx % 8) || (ldw % 8) || (((uintptr_t)x) & 15) || (((uintptr_t)Wt) & 15)) {
+        fw_set_error("fw_conv_gemm_bf16: C must be a positive multiple of 64, ldx / ldw % 8 == 0, x / W 16-byte aligned"); return FW_E_BADARG; }
+    if (T < 1 || H < 1 || W < 1 || kt < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || (up != 1 && up != 2) ||
+        t0 < 0 || t0 + nt > T) { fw_set_error("fw_conv_gemm_bf16: bad geometry"); return FW_E_BADARG; }
+    if (out_dtype != FW_DT_BF16 && out_dtype != FW_DT_F32) { fw_set_error("fw_conv_gemm_bf16: bad out_dtype"); return FW_E_BADARG; }
+    if (res_dtype != FW_DT_NONE && res == nullptr) { fw_set_error("fw_conv_gemm_bf16: res_dtype set but res NULL"); return FW_E_BADARG; }
+    const int Hu = H * up, Wu = W * up;
+    const int Ho = (Hu + 2 * ph - kh) / sh + 1, Wo = (Wu + 2 * pw - kw) / sw + 1;
+    if (Ho < 1 || Wo < 1) { fw_set_error("fw_conv_gemm_bf16: empty output map"); return FW_E_BADARG; }
+    // the kernels keep (frame | yo*sh | xo*sw) of a row in 8 + 12 + 12 bits
+    if (T > 255 || (Ho - 1) * sh > 4095 || (Wo - 1) * sw > 4095) {
+        fw_set_error("fw_conv_gemm_bf16: T <= 255 and (Ho-1)*sh, (Wo-1)*sw <= 4095 required (chunk the volume)"); return FW_E_BADARG; }
+    const int64_t M64 = (int64_t)nt * Ho * Wo;
+    const int64_t K64 = (int64_t)kt * kh * kw * C;
+    if (M64 > 0x7fffffff || K64 > 0x7fffffff || ldw < K64) { fw_set_error("fw_conv_gemm_bf16: M or K too large, or ldw < taps * C"); return FW_E_BADARG; }
+    GemmArgs p;
+    p.A = x; p.lda = ldx; p.W = Wt; p.ldw = ldw; p.C = Cout; p.ldc = ldc; p.out_dtype = out_dtype;
+    p.M = (int)M64; p.N = N; p.K = (int)K64; p.bias = bias; p.act = act; p.g1 = g1; p.g0 = g0;
+    p.res = res; p.ldr = ldr; p.res_dtype = res ? res_dtype : FW_DT_NONE;
+    p.cv.T = T; p.cv.H = H; p.cv.W = W; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.kt = kt; p.cv.kh = kh; p.cv.kw = kw;
+    p.cv.sh = sh; p.cv.sw = sw; p.cv.ph = ph; p.cv.pw = pw; p.cv.ups = up == 2 ? 1 : 0; p.cv.t0 = t0; p.cv.cpt = C / BK;
+    const int M = p.M, K = p.K;
+    // same tile rule as fw_gemm_bf16 (no tail peel: a ragged last band of a feature map with 10^5 .. 10^7 rows costs nothing)
+    bool big = M >= 2048 && (N >= 1024 || (N >= 256 && (int64_t)(M / TM) * ((N + TN - 1) / TN) >= 512));
+    const int forced = fw_get_option(FW_OPT_GEMM_TILE);
+    if (forced == 128) big = false;
+    if (forced == 256) big = true;
+    const uintptr_t cmask = (out_dtype == FW_DT_F32) ? 15 : 7;
+    const uintptr_t rmask = (res_dtype == FW_DT_F32) ? 15 : 7;
+    if ((N % 4) || (ldc % 4) || (((uintptr_t)Cout) & cmask) || (res && ((ldr % 4) || (((uintptr_t)res) & rmask)))) big = false;
+    if ((((uintptr_t)bias) | ((uintptr_t)g1) | ((uintptr_t)g0)) & 15) big = false;
+    hipStream_t st = (hipStream_t)stream;
+    if (big && K >= 4 * BK) {
+        p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
+        hipLaunchKernelGGL((gemm_bf16_pp2_kernel<false, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, st, p);
+        return (int)hipGetLastError();
+    }
+    p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
+    if (nwg > 0x7fffffff) { fw_set_error("fw_conv_gemm_bf16: grid too large"); return FW_E_BADARG; }
+    hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 

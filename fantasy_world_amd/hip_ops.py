@@ -23,7 +23,7 @@ SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_attention_workspace_bytes", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
     "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_debug_gemm_timestamps", "fw_control_patchify", "fw_im2col3x3",
-    "fw_im2col", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
+    "fw_im2col", "fw_conv_gemm_bf16", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
     "fw_fp8_quant_rows", "fw_gemm_fp8",
@@ -66,6 +66,7 @@ def load_library(path: str = LIB_PATH):
         "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+        "fw_conv_gemm_bf16": [vp, i64] + [i32] * 14 + [vp, i64, vp, i64, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
         "fw_softmax_rows": [vp, i64, vp, i64, i32, i32, i32, f32, vp],
         "fw_fp8_quant_rows": [vp, i64, vp, i64, vp, i32, i32, i32, vp],
         "fw_gemm_fp8": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
@@ -88,7 +89,7 @@ def load_library(path: str = LIB_PATH):
         fn.argtypes = args
     lib.fw_attention_workspace_bytes.restype = i64
     lib.fw_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    if lib.fw_abi_version() != 7:
+    if lib.fw_abi_version() != 8:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -401,6 +402,31 @@ class HipOps:
         out = torch.empty(nt * Ho * Wo, kt * kh * kw * C, dtype=torch.bfloat16, device=self.device)
         _check(self.lib.fw_im2col(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), C, T, H, W, kt, kh, kw, sh, sw,
                                   ph, pw, up, t0, nt, int(relu_in), self._stream()), "fw_im2col")
+        return out
+
+    def conv_gemm(self, x, T, H, W, lin, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, ph=None, pw=None, up=1, act=None, res=None,
+                  out_f32=False, out=None):
+        """The convolution as ONE implicit-GEMM launch (fw_conv_gemm_bf16): bit-identical to linear(im2col(x, ...), lin, ...)
+        without ever writing the gathered matrix.  x [T*H*W, C], C % 64 == 0; lin packed tap-major ([N, kt*kh*kw*C])."""
+        self._bf16_rows(x)
+        self._check_dev(x, res, out)
+        assert x.shape[0] == T * H * W and not lin.fp8
+        nt = T - t0 if nt is None else nt
+        ph, pw = kh // 2 if ph is None else ph, kw // 2 if pw is None else pw
+        C = x.shape[1]
+        assert C % 64 == 0 and lin.K == kt * kh * kw * C, (C, lin.K, kt, kh, kw)
+        Ho, Wo = (H * up + 2 * ph - kh) // sh + 1, (W * up + 2 * pw - kw) // sw + 1
+        M = nt * Ho * Wo
+        if out is None:
+            out = torch.empty(M, lin.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=self.device)
+        assert out.shape == (M, lin.N) and out.stride(1) == 1
+        if res is not None:
+            assert res.shape == (M, lin.N) and res.stride(1) == 1
+        _check(self.lib.fw_conv_gemm_bf16(
+            x.data_ptr(), x.stride(0), C, T, H, W, kt, kh, kw, sh, sw, ph, pw, up, t0, nt,
+            lin.w.data_ptr(), lin.w.stride(0), out.data_ptr(), out.stride(0), _dt(out), lin.N,
+            _ptr(lin.b), ACT[act], None, None, _ptr(res), 0 if res is None else res.stride(0),
+            FW_DT_NONE if res is None else _dt(res), self._stream()), "fw_conv_gemm_bf16")
         return out
 
     def softmax_rows(self, s, scale, cols_pad):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 7
+#define FW_ABI_VERSION 8
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -229,6 +229,22 @@ int fw_im2col3x3(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int
  */
 int fw_im2col(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int C, int T, int H, int W, int kt, int kh, int kw,
               int sh, int sw, int ph, int pw, int up, int t0, int nt, int relu_in, void* stream);
+
+/*
+ * The same convolutions as ONE kernel (implicit GEMM): out[(t - t0, yo, xo)][n] = epi(sum_{tap, c} x[..tap..][c] * Wt[n][tap*C + c])
+ * with fw_im2col's geometry and fw_gemm_bf16's epilogue (bias, act, per-column affine, residual with `ldr`, bf16 / f32 output).
+ * The gathered matrix is never written: the k-slab (64 channels of one tap) of a tile row is DMA'd to LDS straight from the row of
+ * x that tap points at (128 B of zeros outside the volume), so the convolution reads x (L2-resident neighbours) instead of
+ * writing and re-reading taps x C values per pixel.  Bit-identical to fw_im2col + fw_gemm_bf16 (same kernel, same k-order).
+ * Requires C % 64 == 0 (the feature maps of the geometry heads / VAE decoder are padded that way), T <= 255 and
+ * (Ho-1)*sh, (Wo-1)*sw <= 4095; Wt [N][ldw >= kt*kh*kw*C] tap-major as for fw_im2col.  nn.Conv2d / CausalConv3d call sites:
+ * vggt/heads/dpt_head.py:82-87, 352-397, 412-428; wan/modules/vae_modified.py:17-36; diffsynth_wan21/models/wan_video_vae.py:92-99.
+ */
+int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, int H, int W, int kt, int kh, int kw,
+                      int sh, int sw, int ph, int pw, int up, int t0, int nt,
+                      const uint16_t* Wt, int64_t ldw, void* out, int64_t ldo, int out_dtype, int N,
+                      const float* bias, int act, const float* g1, const float* g0,
+                      const void* res, int64_t ldr, int res_dtype, void* stream);
 
 /* F.interpolate(mode="bilinear", align_corners=True) (custom_interpolate, vggt/heads/dpt_head.py:538-566):
  * x [N*h*w][C] -> out [N*H*W][C]. */

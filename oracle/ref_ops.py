@@ -227,6 +227,13 @@ class TorchRefOps:
                     cols.append(v[t0 + dt:t0 + dt + nt, dy:dy + (Ho - 1) * sh + 1:sh, dx:dx + (Wo - 1) * sw + 1:sw])
         return self._r(torch.cat(cols, dim=-1).reshape(nt * Ho * Wo, kt * kh * kw * C))
 
+
+    def conv_gemm(self, x, T, H, W, lin, kt, kh, kw, sh=1, sw=1, t0=0, nt=None, ph=None, pw=None, up=1, act=None, res=None,
+                  out_f32=False, out=None):
+        """The op the HIP side runs as one implicit-GEMM kernel (fw_conv_gemm_bf16): by definition gather + linear."""
+        cols = self.im2col(x, T, H, W, kt, kh, kw, sh, sw, t0, nt, False, ph, pw, up)
+        return self.linear(cols, lin, act=act, res=res, out_f32=out_f32, out=out)
+
     def resize_bilinear(self, x, N, h, w, H, W):
         """F.interpolate(mode='bilinear', align_corners=True) on [N*h*w, C] -> [N*H*W, C] (dpt_head.py:538-566)."""
         C = x.shape[1]

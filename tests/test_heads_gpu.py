@@ -71,6 +71,61 @@ def test_im2col_then_gemm_is_the_convolution(ops, parity, request):
     parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-3)
 
 
+CONV_GEMM_CASES = [  # T, H, W, C, N, kt, kh, kw, sh, sw, t0, nt, up, tile
+    (3, 10, 12, 64, 64, 3, 3, 3, 1, 1, 0, None, 1, 0),       # CausalConv3d 3x3x3, 128x128 kernel
+    (2, 21, 17, 128, 256, 1, 3, 3, 1, 1, 0, None, 1, 0),     # Conv2d 3x3, two k-slabs per tap
+    (1, 37, 37, 64, 128, 1, 3, 3, 2, 2, 0, None, 1, 0),      # stride 2 (dpt_head resize_layers[3])
+    (3, 9, 11, 128, 128, 1, 3, 3, 1, 1, 0, None, 2, 0),      # on the nearest x2 up-sampled map (VAE Resample)
+    (6, 8, 8, 64, 128, 3, 1, 1, 1, 1, 0, None, 1, 0),        # time_conv (3,1,1)
+    (7, 6, 5, 64, 64, 3, 3, 3, 1, 1, 2, 3, 1, 0),            # frame window t0 = 2, nt = 3
+    (2, 63, 80, 64, 256, 1, 3, 3, 1, 1, 0, None, 1, 256),    # the 256x256 ping-pong kernel (forced), ragged last band
+    (3, 48, 40, 128, 512, 3, 3, 3, 1, 1, 1, 2, 1, 256),      # 256x256 kernel, 27 taps x 2 slabs, two column tiles
+    (2, 30, 36, 64, 256, 1, 3, 3, 1, 1, 0, None, 2, 256),    # 256x256 kernel on the up-sampled map
+]
+
+
+@pytest.mark.parametrize("T,H,W,C,N,kt,kh,kw,sh,sw,t0,nt,up,tile", CONV_GEMM_CASES)
+@pytest.mark.parametrize("epi", ["plain", "relu_res_f32"])
+def test_conv_gemm_equals_gather_plus_gemm(ops, T, H, W, C, N, kt, kh, kw, sh, sw, t0, nt, up, tile, epi):
+    """fw_conv_gemm_bf16 (implicit GEMM: the tap gather is the A tile's DMA source address) against fw_im2col + fw_gemm_bf16: the
+    same kernel body, the same k-order per output element -> BIT-IDENTICAL, on both tile kernels, with strides, the up-sampled
+    map, frame windows and the fused epilogue."""
+    x = dev(rnd(T * H * W, C, seed=11))
+    K = kt * kh * kw * C
+    lin = ops.pack_linear(rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13, scale=0.1))
+    cols = ops.im2col(x, T, H, W, kt, kh, kw, sh, sw, t0, nt, False, up=up)
+    kw_epi = {}
+    if epi != "plain":
+        kw_epi = dict(act="relu", out_f32=True, res=torch.randn(cols.shape[0], N, generator=torch.Generator().manual_seed(14)).cuda())
+    ops.set_option("gemm_tile", tile)
+    try:
+        want = ops.linear(cols, lin, **kw_epi)
+        got = ops.conv_gemm(x, T, H, W, lin, kt, kh, kw, sh=sh, sw=sw, t0=t0, nt=nt, up=up, **kw_epi)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("gemm_tile", 0)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert torch.equal(got, want)
+
+
+def test_conv_gemm_is_the_convolution(ops, parity, request):
+    """... and against F.conv3d itself (fp32, causal time padding, vae_modified.py:17-36)."""
+    import torch.nn.functional as F
+    T, H, W, C, N = 5, 6, 7, 64, 128
+    x, w, b = rnd(T * H * W, C, seed=2), rnd(N, C, 3, 3, 3, seed=3, scale=(27 * C) ** -0.5), rnd(N, seed=4, scale=0.1)
+    vol = x.view(T, H, W, C).permute(3, 0, 1, 2)[None]
+    want = F.conv3d(F.pad(vol, (1, 1, 1, 1, 2, 0)), w, b)[0].permute(1, 2, 3, 0).reshape(T * H * W, N)
+    lin = ops.pack_linear(w.permute(0, 2, 3, 4, 1).reshape(N, 27 * C), b)
+    got = ops.conv_gemm(dev(x), T, H, W, lin, 3, 3, 3, out_f32=True)
+    parity.check(f"op/{request.node.name}/0", rel_l2(got, want), 1e-3)
+
+
+def test_conv_gemm_rejects_what_it_cannot_pack(ops):
+    lin = ops.pack_linear(rnd(64, 640, seed=1), None)
+    with pytest.raises(AssertionError):
+        ops.conv_gemm(dev(rnd(16, 72, seed=2)), 1, 4, 4, lin, 1, 3, 3)          # C % 64 != 0: the gather path serves these
+
+
 @pytest.mark.parametrize("N,h,w,H,W,C", [(2, 4, 6, 8, 12, 64), (1, 15, 26, 30, 52, 72), (3, 5, 3, 20, 12, 64), (1, 7, 7, 7, 7, 8),
                                          (2, 1, 5, 4, 9, 16)])
 def test_resize_bilinear_align_corners(ops, ref, N, h, w, H, W, C, parity, request):

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--ph", type=int, default=30)
     ap.add_argument("--pw", type=int, default=52)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--gather", action="store_true", help="the older fw_im2col + fw_gemm_bf16 pair instead of the implicit-GEMM convolution")
     a = ap.parse_args()
     hc = fwc.HeadsConfig()
     ops = HipOps("cuda:0")
@@ -27,6 +28,8 @@ def main():
     W = synth.make_heads_weights(hc, device="cuda")
     print(f"weights: {sum(v.numel() for v in W.values())/1e6:.0f} M params in {time.time()-t0:.1f}s", flush=True)
     gh = GeometryHeads(hc, W.__getitem__, ops)
+    gh.implicit_conv = not a.gather
+    print("convolutions:", "gather + GEMM" if a.gather else "implicit GEMM", flush=True)
     del W
     torch.cuda.empty_cache()
     ol = {k: v[None] for k, v in synth.make_output_list(hc, a.frames, a.ph, a.pw, device="cuda").items()}

@@ -32,6 +32,8 @@ def main():
     pl = synth.make_plucker(81, 480, 832, device="cuda").bfloat16()
     timed("pose encoder 81x480x832", lambda: enc.encode(pl))
     dec = VaeDecoder(synth.make_vae_decoder_weights(device="cuda").__getitem__, ops)
+    dec.implicit_conv = "--gather" not in sys.argv      # --gather: the older fw_im2col + fw_gemm_bf16 pair (A/B)
+    print("convolutions:", "implicit GEMM" if dec.implicit_conv else "gather + GEMM", flush=True)
     tile = synth.make_latents(21, 34, 34, device="cuda").bfloat16()
     timed("vae decoder tile 21x34x34", lambda: dec.decode(tile))
     full = synth.make_latents(21, 60, 104, device="cuda").bfloat16()
