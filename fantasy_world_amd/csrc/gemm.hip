@@ -294,8 +294,54 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
     using Q0 = std::integral_constant<int, 0>;
     using Q1 = std::integral_constant<int, 1>;
     if (p.res_dtype == FW_DT_F32) {
-        pass(Q0{}, std::integral_constant<int, FW_DT_F32>{});
-        pass(Q1{}, std::integral_constant<int, FW_DT_F32>{});
+        // fp32 residual stream (the N = 5120 gate + residual GEMMs, 17 % of a step): the residual loads of pass 1 are issued from
+        // inside the store loop of pass 0, each one as soon as the register that held pass 0's value is free and BEFORE the store of
+        // the same rows: their latency runs under pass 0's stores and pass 1's LDS transpose, and waiting for them never has to wait
+        // for a later store (vmcnt retires in order).  Interleaved A/B (tools/gemm_ab.py): o-projection + residual +1.4 %.
+        f32x4_t rv[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = m0 + grp * 128 + it * 4 + rl;
+            rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (row < p.M && col_ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+        }
+        auto pass2 = [&](auto q_tag) {
+            constexpr int q = decltype(q_tag)::value;
+#pragma unroll
+            for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[2 * q + rb2][nb][r] + bias2[nb];
+                        v = fw_apply_act(v, p.act);
+                        v = fw_affine(v, g12[nb], g02[nb]);
+                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
+                    }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row_l = it * 4 + rl;
+                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
+                const int row = m0 + grp * 128 + q * 64 + row_l;
+                v += rv[it];
+                if (q == 0) {
+                    const int row1 = row + 64;
+                    rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (row1 < p.M && col_ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row1 * p.ldr + gcol);
+                }
+                if (row < p.M && col_ok) {
+                    if (p.out_dtype == FW_DT_F32) {
+                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                    } else {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                    }
+                }
+            }
+        };
+        pass2(Q0{});
+        pass2(Q1{});
     } else if (p.res_dtype == FW_DT_BF16) {
         pass(Q0{}, std::integral_constant<int, FW_DT_BF16>{});
         pass(Q1{}, std::integral_constant<int, FW_DT_BF16>{});

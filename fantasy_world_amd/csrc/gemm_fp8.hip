@@ -63,6 +63,64 @@ __device__ __forceinline__ void epilogue_fp8(const QArgs& p, char* smem, f32x16_
         if (p.g0) g04 = *(const f32x4_t*)(p.g0 + gcol);
     }
     const int act = p.act;
+    if (p.res_dtype == FW_DT_F32) {
+        // fp32 residual stream (o-projection / ffn2 of a DiT block): the scheme of the bf16 kernel's epilogue_256 -- all 16 residual
+        // loads of a 64-row pass in flight before the LDS transpose, and pass 1's loads issued from inside pass 0's store loop, ahead
+        // of the stores.  With the mainloop twice as fast as in bf16, the epilogue weighs twice as much here.
+        f32x4_t rv[16];
+        float sa[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = m0 + grp * 128 + it * 4 + rl;
+            rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            sa[it] = 0.f;
+            if (row < p.M && col_ok) { rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol); sa[it] = p.scale_a[row]; }
+        }
+        auto pass = [&](auto q_tag) {
+            constexpr int q = decltype(q_tag)::value;              // compile-time: acc[] must never be indexed dynamically
+#pragma unroll
+            for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = acc[2 * q + rb2][nb][r];
+                    }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row_l = it * 4 + rl;
+                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
+                const int row = m0 + grp * 128 + q * 64 + row_l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], sa[it], bias4[j]);
+                if (act != FW_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], g14[j], g04[j]);
+                v += rv[it];
+                if (q == 0) {
+                    const int row1 = row + 64;
+                    rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    sa[it] = 0.f;
+                    if (row1 < p.M && col_ok) { rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row1 * p.ldr + gcol); sa[it] = p.scale_a[row1]; }
+                }
+                if (row < p.M && col_ok) {
+                    if (p.out_dtype == FW_DT_F32) {
+                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                    } else {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                    }
+                }
+            }
+        };
+        pass(std::integral_constant<int, 0>{});
+        pass(std::integral_constant<int, 1>{});
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
 #pragma unroll
