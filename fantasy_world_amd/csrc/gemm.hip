@@ -83,6 +83,15 @@ __device__ __forceinline__ const char* conv_src(const GemmArgs& p, unsigned pack
     return ok ? src : (const char*)g_conv_zero + chunk_bytes;
 }
 
+// fw_apply_act with the activation as a compile-time constant (straight-line code inside the unrolled element loops)
+template <int ACT> __device__ __forceinline__ float fw_apply_act_ct(float v) {
+    if (ACT == FW_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == FW_ACT_GELU_TANH) return fw_gelu_tanh(v);
+    if (ACT == FW_ACT_GELU_ERF) return fw_gelu_erf(v);
+    if (ACT == FW_ACT_SILU) return fw_silu(v);
+    return v;
+}
+
 template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -189,29 +198,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------
+    // (the activation is a compile-time parameter of the body, selected once: see epilogue_256)
+    auto epilogue = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int col = n0 + wn * 64 + nb * 32 + fi;
-        const bool col_ok = col < p.N;
-        const float bias = (p.bias && col_ok) ? p.bias[col] : 0.f;
-        const float g1 = (p.g1 && col_ok) ? p.g1[col] : 1.f;
-        const float g0 = (p.g0 && col_ok) ? p.g0[col] : 0.f;
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = n0 + wn * 64 + nb * 32 + fi;
+            const bool col_ok = col < p.N;
+            const float bias = (p.bias && col_ok) ? p.bias[col] : 0.f;
+            const float g1 = (p.g1 && col_ok) ? p.g1[col] : 1.f;
+            const float g0 = (p.g0 && col_ok) ? p.g0[col] : 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row < p.M && col_ok) {
-                    float v = acc[rb][nb][r] + bias;
-                    v = fw_apply_act(v, p.act);
-                    v = fw_affine(v, g1, g0);
-                    if (p.res_dtype == FW_DT_F32) v += ((const float*)p.res)[(int64_t)row * p.ldr + col];
-                    else if (p.res_dtype == FW_DT_BF16) v += bf16_bits_to_f32(((const uint16_t*)p.res)[(int64_t)row * p.ldr + col]);
-                    if (p.out_dtype == FW_DT_F32) ((float*)p.C)[(int64_t)row * p.ldc + col] = v;
-                    else ((uint16_t*)p.C)[(int64_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < p.M && col_ok) {
+                        float v = acc[rb][nb][r] + bias;
+                        v = fw_apply_act_ct<ACT>(v);
+                        v = fw_affine(v, g1, g0);
+                        if (p.res_dtype == FW_DT_F32) v += ((const float*)p.res)[(int64_t)row * p.ldr + col];
+                        else if (p.res_dtype == FW_DT_BF16) v += bf16_bits_to_f32(((const uint16_t*)p.res)[(int64_t)row * p.ldr + col]);
+                        if (p.out_dtype == FW_DT_F32) ((float*)p.C)[(int64_t)row * p.ldc + col] = v;
+                        else ((uint16_t*)p.C)[(int64_t)row * p.ldc + col] = f32_to_bf16_bits(v);
+                    }
                 }
             }
         }
+    };
+    switch (p.act) {
+        case FW_ACT_RELU: epilogue(std::integral_constant<int, FW_ACT_RELU>{}); break;
+        case FW_ACT_GELU_TANH: epilogue(std::integral_constant<int, FW_ACT_GELU_TANH>{}); break;
+        case FW_ACT_GELU_ERF: epilogue(std::integral_constant<int, FW_ACT_GELU_ERF>{}); break;
+        case FW_ACT_SILU: epilogue(std::integral_constant<int, FW_ACT_SILU>{}); break;
+        default: epilogue(std::integral_constant<int, FW_ACT_NONE>{}); break;
     }
 }
 
@@ -220,9 +240,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 // through a private 16 KiB region (fp32, row stride 256 B), so that global traffic is row-contiguous 16-B (fp32) / 8-B
 // (bf16) per lane: residual loads and output stores touch whole 128-B lines instead of 2-4 B per lane at a row stride.
 // bias / activation / per-column affine are applied on the way in (column == lane in the accumulator layout).
-__device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x16_t (&acc)[4][2], int wave, int grp, int wn,
-                                             int fi, int hi, int lane, int m0, int n0) {
-    char* reg = smem + wave * 16384;
+//
+// Activation, residual type and output type are COMPILE-TIME parameters of the body, selected once per wave (round 2, read off
+// the ISA: with `switch (p.act)` inside the element loop every one of the 256 accumulator values of a wave walked a chain of scalar
+// compares and taken branches -- 35 000 cycles = 17-19 us of a 145 us tile, measured with tools/gemm_timeline.py and as the
+// intercept of time against K, tools/probes/gemm_intercept.py: 20 us fixed per tile plain, 32 us with the fp32 residual).
+
+template <int ACT, int RES, int OUT>
+__device__ __forceinline__ void epilogue_256_body(const GemmArgs& p, char* reg, f32x16_t (&acc)[4][2], int grp, int wn,
+                                                  int fi, int hi, int lane, int m0, int n0) {
     float bias2[2], g12[2], g02[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -236,28 +262,28 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
     const int c4 = (lane & 15) * 4;        // first of this lane's 4 columns
     const int gcol = n0 + wn * 64 + c4;
     const bool col_ok = gcol < p.N;
-    // One 64-row pass: (1) ALL 16 residual loads of the pass are issued first -- 16 KiB per wave, 128 KiB per CU in flight, so the
-    // HBM latency of the fp32 stream is paid once per pass and runs under the LDS transpose instead of once per 4 rows --
-    // (2) accumulators -> LDS with bias / activation / affine, (3) row-contiguous read-back, + residual, 16-B stores.
-    auto pass = [&](auto q_tag, auto res_tag) {
-        constexpr int q = decltype(q_tag)::value;              // compile-time: acc[] must never be indexed dynamically
-        constexpr int RES = decltype(res_tag)::value;          // FW_DT_NONE / FW_DT_BF16 / FW_DT_F32
-        f32x4_t rv[16];
-        u32x2_t rw[16];
-        if (RES != FW_DT_NONE) {
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = m0 + grp * 128 + q * 64 + it * 4 + rl;
-                const bool ok = row < p.M && col_ok;
-                if (RES == FW_DT_F32) {
-                    rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    if (ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
-                } else {
-                    rw[it] = u32x2_t{0u, 0u};
-                    if (ok) rw[it] = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
-                }
-            }
+    // Residual values of a 64-row pass: ALL 16 loads are in flight before the LDS transpose (16 KiB per wave, 128 KiB per CU), and
+    // the loads of pass 1 are issued from inside the store loop of pass 0 -- each as soon as the register that held pass 0's value
+    // is free and BEFORE the store of the same rows: their latency runs under pass 0's stores and pass 1's transpose, and waiting
+    // for them never has to wait for a later store (vmcnt retires in order).
+    f32x4_t rv[16];
+    u32x2_t rw[16];
+    auto load_res = [&](int it, int row) __attribute__((always_inline)) {
+        const bool ok = row < p.M && col_ok;
+        if (RES == FW_DT_F32) {
+            rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
+        } else if (RES == FW_DT_BF16) {
+            rw[it] = u32x2_t{0u, 0u};
+            if (ok) rw[it] = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
         }
+    };
+    if (RES != FW_DT_NONE) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) load_res(it, m0 + grp * 128 + it * 4 + rl);
+    }
+    auto pass = [&](auto q_tag) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_tag)::value;              // compile-time: acc[] must never be indexed dynamically
 #pragma unroll
         for (int rb2 = 0; rb2 < 2; ++rb2)
 #pragma unroll
@@ -265,7 +291,7 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[2 * q + rb2][nb][r] + bias2[nb];
-                    v = fw_apply_act(v, p.act);
+                    v = fw_apply_act_ct<ACT>(v);
                     v = fw_affine(v, g12[nb], g02[nb]);
                     const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
@@ -281,8 +307,9 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
                 v[0] += __uint_as_float(rw[it][0] << 16); v[1] += __uint_as_float(rw[it][0] & 0xffff0000u);
                 v[2] += __uint_as_float(rw[it][1] << 16); v[3] += __uint_as_float(rw[it][1] & 0xffff0000u);
             }
+            if (q == 0 && RES != FW_DT_NONE) load_res(it, row + 64);
             if (row < p.M && col_ok) {
-                if (p.out_dtype == FW_DT_F32) {
+                if (OUT == FW_DT_F32) {
                     *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
                 } else {
                     u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
@@ -291,63 +318,36 @@ __device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x
             }
         }
     };
-    using Q0 = std::integral_constant<int, 0>;
-    using Q1 = std::integral_constant<int, 1>;
-    if (p.res_dtype == FW_DT_F32) {
-        // fp32 residual stream (the N = 5120 gate + residual GEMMs, 17 % of a step): the residual loads of pass 1 are issued from
-        // inside the store loop of pass 0, each one as soon as the register that held pass 0's value is free and BEFORE the store of
-        // the same rows: their latency runs under pass 0's stores and pass 1's LDS transpose, and waiting for them never has to wait
-        // for a later store (vmcnt retires in order).  Interleaved A/B (tools/gemm_ab.py): o-projection + residual +1.4 %.
-        f32x4_t rv[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = m0 + grp * 128 + it * 4 + rl;
-            rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (row < p.M && col_ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
-        }
-        auto pass2 = [&](auto q_tag) {
-            constexpr int q = decltype(q_tag)::value;
-#pragma unroll
-            for (int rb2 = 0; rb2 < 2; ++rb2)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[2 * q + rb2][nb][r] + bias2[nb];
-                        v = fw_apply_act(v, p.act);
-                        v = fw_affine(v, g12[nb], g02[nb]);
-                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = v;
-                    }
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row_l = it * 4 + rl;
-                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
-                const int row = m0 + grp * 128 + q * 64 + row_l;
-                v += rv[it];
-                if (q == 0) {
-                    const int row1 = row + 64;
-                    rv[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                    if (row1 < p.M && col_ok) rv[it] = *(const f32x4_t*)((const float*)p.res + (int64_t)row1 * p.ldr + gcol);
-                }
-                if (row < p.M && col_ok) {
-                    if (p.out_dtype == FW_DT_F32) {
-                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
-                    } else {
-                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
-                    }
-                }
-            }
-        };
-        pass2(Q0{});
-        pass2(Q1{});
-    } else if (p.res_dtype == FW_DT_BF16) {
-        pass(Q0{}, std::integral_constant<int, FW_DT_BF16>{});
-        pass(Q1{}, std::integral_constant<int, FW_DT_BF16>{});
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+}
+
+// Dispatch (wave-uniform, once per wave): 5 activations x 3 residual types x 2 output types = 30 straight-line bodies.
+template <int RES, int OUT>
+__device__ __forceinline__ void epilogue_256_any_act(const GemmArgs& p, char* reg, f32x16_t (&acc)[4][2], int grp, int wn,
+                                                     int fi, int hi, int lane, int m0, int n0) {
+    switch (p.act) {
+        case FW_ACT_RELU: epilogue_256_body<FW_ACT_RELU, RES, OUT>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0); break;
+        case FW_ACT_GELU_TANH: epilogue_256_body<FW_ACT_GELU_TANH, RES, OUT>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0); break;
+        case FW_ACT_GELU_ERF: epilogue_256_body<FW_ACT_GELU_ERF, RES, OUT>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0); break;
+        case FW_ACT_SILU: epilogue_256_body<FW_ACT_SILU, RES, OUT>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0); break;
+        default: epilogue_256_body<FW_ACT_NONE, RES, OUT>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0); break;
+    }
+}
+
+__device__ __forceinline__ void epilogue_256(const GemmArgs& p, char* smem, f32x16_t (&acc)[4][2], int wave, int grp, int wn,
+                                             int fi, int hi, int lane, int m0, int n0) {
+    char* reg = smem + wave * 16384;
+    const bool f32out = p.out_dtype == FW_DT_F32;
+    if (p.res_dtype == FW_DT_NONE) {
+        if (f32out) epilogue_256_any_act<FW_DT_NONE, FW_DT_F32>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0);
+        else epilogue_256_any_act<FW_DT_NONE, FW_DT_BF16>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0);
+    } else if (p.res_dtype == FW_DT_F32) {
+        if (f32out) epilogue_256_any_act<FW_DT_F32, FW_DT_F32>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0);
+        else epilogue_256_any_act<FW_DT_F32, FW_DT_BF16>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0);
     } else {
-        pass(Q0{}, std::integral_constant<int, FW_DT_NONE>{});
-        pass(Q1{}, std::integral_constant<int, FW_DT_NONE>{});
+        if (f32out) epilogue_256_any_act<FW_DT_BF16, FW_DT_F32>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0);
+        else epilogue_256_any_act<FW_DT_BF16, FW_DT_BF16>(p, reg, acc, grp, wn, fi, hi, lane, m0, n0);
     }
 }
 
@@ -378,8 +378,9 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
         if (p.g0) g04 = *(const f32x4_t*)(p.g0 + gcol);
     }
     const int act = p.act;
-    auto run = [&](auto res_tag) __attribute__((always_inline)) {
+    auto run = [&](auto res_tag, auto act_tag) __attribute__((always_inline)) {
         constexpr int RES = decltype(res_tag)::value;          // FW_DT_NONE / FW_DT_BF16 / FW_DT_F32
+        constexpr int ACT = decltype(act_tag)::value;          // FW_ACT_*, or -1 = decided per element at run time (rare combinations)
         // residual values of TWO passes at a time (32 loads = 32 KiB per wave, 128 KiB per CU in flight: with four waves per CU one
         // pass alone leaves the HBM latency half exposed; the fragment / staging registers of the mainloop are dead here)
         f32x4_t rv[2][16];
@@ -415,9 +416,12 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
                 f32x4_t v = *(const f32x4_t*)(reg + row_l * 512 + c4 * 4);
                 const int row = m0 + wm * 128 + rb * 32 + row_l;
                 v += bias4;
-                if (act != FW_ACT_NONE) {
+                if (ACT < 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
+                } else if (ACT != FW_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fw_apply_act_ct<(ACT < 0 ? 0 : ACT)>(v[j]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], g14[j], g04[j]);
@@ -446,9 +450,23 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
         load_res(R2{}); load_res(R3{});
         pass(R2{}); pass(R3{});
     };
-    if (p.res_dtype == FW_DT_F32) run(std::integral_constant<int, FW_DT_F32>{});
-    else if (p.res_dtype == FW_DT_BF16) run(std::integral_constant<int, FW_DT_BF16>{});
-    else run(std::integral_constant<int, FW_DT_NONE>{});
+    // the activation is a compile-time parameter of the body wherever the forward uses one (plain outputs); see epilogue_256
+    using ActNone = std::integral_constant<int, FW_ACT_NONE>;
+    using ActAny = std::integral_constant<int, -1>;
+    if (p.res_dtype == FW_DT_F32) {
+        if (act == FW_ACT_NONE) run(std::integral_constant<int, FW_DT_F32>{}, ActNone{}); else run(std::integral_constant<int, FW_DT_F32>{}, ActAny{});
+    } else if (p.res_dtype == FW_DT_BF16) {
+        if (act == FW_ACT_NONE) run(std::integral_constant<int, FW_DT_BF16>{}, ActNone{}); else run(std::integral_constant<int, FW_DT_BF16>{}, ActAny{});
+    } else {
+        using R0 = std::integral_constant<int, FW_DT_NONE>;
+        switch (act) {
+            case FW_ACT_RELU: run(R0{}, std::integral_constant<int, FW_ACT_RELU>{}); break;
+            case FW_ACT_GELU_TANH: run(R0{}, std::integral_constant<int, FW_ACT_GELU_TANH>{}); break;
+            case FW_ACT_GELU_ERF: run(R0{}, std::integral_constant<int, FW_ACT_GELU_ERF>{}); break;
+            case FW_ACT_SILU: run(R0{}, std::integral_constant<int, FW_ACT_SILU>{}); break;
+            default: run(R0{}, ActNone{}); break;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -491,8 +509,13 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
 // (TS, tools/gemm_timeline.py) stamps s_memtime at the phase boundaries.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ unsigned long long g_gemm_ts[2 * 64];     // TIMING build: [group][slab 0..3][phase 0..3][start | end of work]
+// TIMING build, per work-group (tile): s_memrealtime (100 MHz) at entry, after the prologue barrier, at the end of the mainloop, at
+// the end of the epilogue (stores issued), after the stores have drained; [5] = HW_ID (which CU ran it).  tools/gemm_timeline.py
+// rebuilds the per-CU timeline from it: prologue / mainloop / epilogue per tile and the gap between consecutive tiles on a CU.
+constexpr int TILE_TS_MAX = 8192;
+__device__ unsigned long long g_gemm_tile_ts[TILE_TS_MAX * 6];
 
-template <bool TS, bool CONV>
+template <int TS, bool CONV>     // TS: 0 = product, 1 = TIMING build (phase + tile stamps), 2 = tile stamps only (does not perturb the loop)
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
 
@@ -555,11 +578,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8_t afr[2][4], bfr[2][4];
 
+    const bool tile_ts = TS != 0 && wave == 0 && lane == 0 && blockIdx.x < TILE_TS_MAX;
+    if (tile_ts) {
+        g_gemm_tile_ts[blockIdx.x * 6 + 0] = __builtin_amdgcn_s_memrealtime();
+        g_gemm_tile_ts[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+    }
     const int nk = p.K / BK;       // >= 4 (launcher)
     FW_PP_ISSUE6(0, 0); FW_PP_ISSUE2(0, 0);
     FW_PP_ISSUE6(1, 1); FW_PP_ISSUE2(1, 1);
     fw_wait_vm<8>();
     FW_BARRIER();
+    if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 1] = __builtin_amdgcn_s_memrealtime();
     if (grp == 1) FW_BARRIER();
 
     int kt = 0;
@@ -568,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
         const int st = kt & 1;
         const char* base = smem + st * STAGE2;
         // TIMING build: s_memtime at the start (barrier passed) and at the end of the work of every phase, slabs 16..19, work-group 0
-        const bool ts_on = TS && blockIdx.x == 0 && wn == 0 && kt >= 16 && kt < 20;
+        const bool ts_on = TS == 1 && blockIdx.x == 0 && wn == 0 && kt >= 16 && kt < 20;
         auto stamp = [&](int phase, int which) {
             if (ts_on) {
                 const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -640,7 +669,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     slab(F{}, T{}, F{});
     slab(F{}, F{}, F{});
     if (grp == 0) FW_BARRIER();
+    if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 2] = __builtin_amdgcn_s_memrealtime();
     epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
+    if (TS != 0) {
+        if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 3] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -897,9 +932,11 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         if (kern == 5 || (kern == 4 && K <= 1280)) {
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<true, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+        } else if (fw_get_option(FW_OPT_GEMM_VAR) & 4) {
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<2, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // tile stamps only
         } else {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<false, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<0, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);
         }
         return (int)hipGetLastError();
     }
@@ -950,7 +987,7 @@ extern "C" int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, i
     hipStream_t st = (hipStream_t)stream;
     if (big && K >= 4 * BK) {
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
-        hipLaunchKernelGGL((gemm_bf16_pp2_kernel<false, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, st, p);
+        hipLaunchKernelGGL((gemm_bf16_pp2_kernel<0, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, st, p);
         return (int)hipGetLastError();
     }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
@@ -962,8 +999,11 @@ extern "C" int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, i
 
 // Measurement hook (tools/gemm_timeline.py): the phase timestamps written by the TIMING build of the ping-pong kernel.
 extern "C" int fw_debug_gemm_timestamps(unsigned long long* host_out, int n) {
-    if (n <= 0 || n > 128) { fw_set_error("fw_debug_gemm_timestamps: n must be in 1..128"); return FW_E_BADARG; }
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_ts), sizeof(unsigned long long) * n);
+    // n <= 128: the phase stamps; n = 128 + 6 * tiles: followed by the per-tile stamps of the first `tiles` work-groups
+    if (n <= 0 || n > 128 + 6 * TILE_TS_MAX) { fw_set_error("fw_debug_gemm_timestamps: n out of range"); return FW_E_BADARG; }
+    int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_ts), sizeof(unsigned long long) * (n < 128 ? n : 128));
+    if (rc || n <= 128) return rc;
+    return (int)hipMemcpyFromSymbol(host_out + 128, HIP_SYMBOL(g_gemm_tile_ts), sizeof(unsigned long long) * (n - 128));
 }
 
 extern "C" int fw_gemv_f32(const float* x, const float* W, int64_t ldw, const float* bias, float* out,

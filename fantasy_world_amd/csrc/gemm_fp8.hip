@@ -121,46 +121,78 @@ __device__ __forceinline__ void epilogue_fp8(const QArgs& p, char* smem, f32x16_
         pass(std::integral_constant<int, 1>{});
         return;
     }
+    // no residual (qkv, ffn0 + GELU, ...) or a bf16 one: the activation is a compile-time parameter of the body, selected once per
+    // wave -- with the switch inside the element loop every value walked a chain of scalar compares and taken branches (the bf16
+    // kernel's epilogue_256 has the measurement).  -1 = decided per element (activation AND bf16 residual: not used by the forward).
+    auto body = [&](auto act_tag, auto res_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr int RES = decltype(res_tag)::value;
+        auto pass = [&](auto q_tag) __attribute__((always_inline)) {
+            constexpr int q = decltype(q_tag)::value;              // compile-time: acc[] must never be indexed dynamically
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+            for (int rb2 = 0; rb2 < 2; ++rb2)
 #pragma unroll
-        for (int rb2 = 0; rb2 < 2; ++rb2)
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = acc[2 * q + rb2][nb][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int row_l = rb2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        *(float*)(reg + row_l * 256 + (nb * 32 + fi) * 4) = acc[2 * q + rb2][nb][r];
+                    }
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int row_l = it * 4 + rl;
-            f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
-            const int row = m0 + grp * 128 + q * 64 + row_l;
-            if (row < p.M && col_ok) {
-                const float s = p.scale_a[row];
+            for (int it = 0; it < 16; ++it) {
+                const int row_l = it * 4 + rl;
+                f32x4_t v = *(const f32x4_t*)(reg + row_l * 256 + c4 * 4);
+                const int row = m0 + grp * 128 + q * 64 + row_l;
+                if (row < p.M && col_ok) {
+                    const float s = p.scale_a[row];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], s, bias4[j]);
-                if (act != FW_ACT_NONE) {
+                    for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], s, bias4[j]);
+                    if (ACT < 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
-                }
+                        for (int j = 0; j < 4; ++j) v[j] = fw_apply_act(v[j], act);
+                    } else if (ACT == FW_ACT_RELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], g14[j], g04[j]);
-                if (p.res_dtype == FW_DT_F32) {
-                    v += *(const f32x4_t*)((const float*)p.res + (int64_t)row * p.ldr + gcol);
-                } else if (p.res_dtype == FW_DT_BF16) {
-                    const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
-                    v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
-                }
-                if (p.out_dtype == FW_DT_F32) {
-                    *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
-                } else {
-                    u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    } else if (ACT == FW_ACT_GELU_TANH) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fw_gelu_tanh(v[j]);
+                    } else if (ACT == FW_ACT_GELU_ERF) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fw_gelu_erf(v[j]);
+                    } else if (ACT == FW_ACT_SILU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fw_silu(v[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fw_affine(v[j], g14[j], g04[j]);
+                    if (RES == FW_DT_BF16) {
+                        const u32x2_t rw = *(const u32x2_t*)((const uint16_t*)p.res + (int64_t)row * p.ldr + gcol);
+                        v[0] += __uint_as_float(rw[0] << 16); v[1] += __uint_as_float(rw[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rw[1] << 16); v[3] += __uint_as_float(rw[1] & 0xffff0000u);
+                    }
+                    if (p.out_dtype == FW_DT_F32) {
+                        *(f32x4_t*)((float*)p.C + (int64_t)row * p.ldc + gcol) = v;
+                    } else {
+                        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *(u32x2_t*)((uint16_t*)p.C + (int64_t)row * p.ldc + gcol) = o;
+                    }
                 }
             }
+        };
+        pass(std::integral_constant<int, 0>{});
+        pass(std::integral_constant<int, 1>{});
+    };
+    using R0 = std::integral_constant<int, FW_DT_NONE>;
+    if (p.res_dtype == FW_DT_BF16) {
+        if (act == FW_ACT_NONE) body(std::integral_constant<int, FW_ACT_NONE>{}, std::integral_constant<int, FW_DT_BF16>{});
+        else body(std::integral_constant<int, -1>{}, std::integral_constant<int, FW_DT_BF16>{});
+    } else {
+        switch (act) {
+            case FW_ACT_RELU: body(std::integral_constant<int, FW_ACT_RELU>{}, R0{}); break;
+            case FW_ACT_GELU_TANH: body(std::integral_constant<int, FW_ACT_GELU_TANH>{}, R0{}); break;
+            case FW_ACT_GELU_ERF: body(std::integral_constant<int, FW_ACT_GELU_ERF>{}, R0{}); break;
+            case FW_ACT_SILU: body(std::integral_constant<int, FW_ACT_SILU>{}, R0{}); break;
+            default: body(std::integral_constant<int, FW_ACT_NONE>{}, R0{}); break;
         }
     }
 }
