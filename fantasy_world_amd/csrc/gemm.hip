@@ -3,9 +3,8 @@
 // Three kernels (round 1 carried six; the superseded generations -- first 2-stage staggered kernel, 5-deep half-slab ring,
 // compiler-ordered four-wave kernel, first ping-pong kernel -- were removed in round 2, their numbers are in DESIGN.md section 4):
 //   gemm_bf16_pp2_kernel   256x256x64, 8 waves in two groups running LOAD || MFMA ping-pong: every big token-major GEMM (default)
-//   gemm_bf16_w4b_kernel   256x256x64, 4 waves with 128x128 wave tiles, hand-ordered single instruction stream: GEMMs with a short
-//                          K (<= 1280: VGGT qkv / fc1, bicross output projections), and the INDEPENDENT implementation the
-//                          full-size agreement test compares the default path with (FW_GEMM_KERNEL=5 forces it everywhere)
+//   gemm_bf16_w4b_kernel   256x256x64, 4 waves with 128x128 wave tiles, hand-ordered single instruction stream: the INDEPENDENT
+//                          implementation the full-size agreement tests compare the default path with (FW_GEMM_KERNEL=5)
 //   gemm_bf16_kernel       128x128x64, 4 waves: small / ragged shapes and the <= 128-row M tail of the big ones
 // All stream A and W k-slabs HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip).  LDS rows are 128 B (64 bf16); the
 // 16-byte chunk index is XOR-swizzled with ((row>>1)&7) so that the ds_read_b128 fragment reads of a 16-lane service group hit 16
@@ -902,7 +901,7 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     if ((N % 4) || (ldc % 4) || (((uintptr_t)C) & cmask) || (res && ((ldr % 4) || (((uintptr_t)res) & rmask)))) big = false;
     if ((((uintptr_t)bias) | ((uintptr_t)g1) | ((uintptr_t)g0)) & 15) big = false;   // per-column vectors are read 16 B at a time
     if (big && K >= 4 * BK) {
-        // FW_GEMM_KERNEL: 4 (default) = ping-pong kernel, with the four-wave kernel for short K; 5 = four-wave kernel everywhere
+        // FW_GEMM_KERNEL: 4 (default) = ping-pong kernel; 5 = four-wave kernel (independent implementation, agreement tests)
         const int kern = fw_get_option(FW_OPT_GEMM_KERNEL);
         // Short M tail (VGGT: 32865 rows = 128 full row bands + 97 rows): a 129th band of 256-row tiles costs a whole extra
         // round of the grid (516 tiles on 256 CUs = 3 rounds for 2.02 rounds of work).  Peel it: the full bands go to the 256x256
@@ -927,9 +926,10 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
         if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
         hipStream_t st = (hipStream_t)stream;
-        // short K: prologue and epilogue weigh more than the mainloop's schedule; the four-wave kernel measures +8..12 % there
-        // (VGGT qkv / fc1 at K = 1024, bicross output projections at K = 1152) and -6..-9 % from K = 4096 on
-        if (kern == 5 || (kern == 4 && K <= 1280)) {
+        // (the four-wave kernel used to serve K <= 1280: it measured +8..12 % there -- because its epilogue did not carry the per-element
+        // activation switch the ping-pong kernel's did.  With that gone the ping-pong kernel is 8-15 % faster at K = 1024 / 1152 as
+        // well (tools/gemm_ab.py --short-k), so the four-wave kernel is now only the independent implementation behind FW_GEMM_KERNEL=5.)
+        if (kern == 5) {
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
             hipLaunchKernelGGL((gemm_bf16_pp2_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build

@@ -60,9 +60,10 @@ int fw_abi_version(void);
  * Each slot is initialised once from the environment variable of the same name.
  */
 #define FW_OPT_GEMM_TILE   0   /* FW_GEMM_TILE: 0 = auto, 128 / 256 = force the tile family */
-#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 4 (default) = 8-wave ping-pong kernel, four-wave kernel for K <= 1280;
+#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 4 (default) = 8-wave ping-pong kernel;
                                   5 = four-wave 128x128-wave-tile kernel for every big GEMM (independent implementation, A/B) */
-#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: 0 (default); bit 1 = TIMING build of the ping-pong kernel (tools/gemm_timeline.py) */
+#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: 0 (default); bit 1 = TIMING build of the ping-pong kernel (phase + tile stamps),
+                                  bit 2 = tile stamps only (tools/gemm_timeline.py) */
 #define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
                                    already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): single-stream kernel (129) for hd
                                    128 / 64, two-segment ping-pong (64) for hd 96.  131 = single-stream with one 64-row wave per

@@ -96,7 +96,7 @@ RING_SHAPES = [(2048, 1024, 256), (2300, 1280, 320), (4095, 1152, 1024), (2051, 
 
 @pytest.mark.parametrize("M,N,K", RING_SHAPES)
 def test_gemm_big_tile_kernels_agree(ops, ref, M, N, K, parity):
-    """The two 256x256 kernels -- 8-wave ping-pong (default) and four-wave 128x128-wave-tile (short K; FW_GEMM_KERNEL=5 forces
+    """The two 256x256 kernels -- 8-wave ping-pong (default) and four-wave 128x128-wave-tile (FW_GEMM_KERNEL=5 selects
     it) -- against the fp32 reference and against each other: same k-order per output element, so they agree BIT FOR BIT."""
     x, w, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23, scale=0.1)
     want = ref.linear(x, ref.pack_linear(w, b), out_f32=True)

@@ -15,14 +15,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--kernels", default="4,5")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=6)
+ap.add_argument("--short-k", action="store_true", help="the K <= 2048 shapes of the VGGT / bicross / adapter GEMMs instead of the DiT ones")
 ap.add_argument("--zeros", action="store_true", help="zero-filled operands: the same instruction stream at a fraction of the switching power (DVFS check)")
 args = ap.parse_args()
 kernels = [tuple(int(v) for v in (k.split(":") + ["0"])[:2]) for k in args.kernels.split(",")]
 ops = HipOps("cuda:0")
 g = torch.Generator(device="cuda").manual_seed(0)
 L = 32760
-for (M, N, K, tag, res) in [(L, 15360, 5120, "qkv", False), (L, 13824, 5120, "ffn0", False), (L, 5120, 5120, "o", False),
-                            (L, 5120, 5120, "o+res", True), (L, 5120, 13824, "ffn2+res", True)]:
+SHAPES = [(L, 15360, 5120, "qkv", False), (L, 13824, 5120, "ffn0", False), (L, 5120, 5120, "o", False),
+          (L, 5120, 5120, "o+res", True), (L, 5120, 13824, "ffn2+res", True)]
+if args.short_k:
+    SHAPES = [(32865, 3072, 1024, "vggt qkv", False), (32865, 4096, 1024, "vggt fc1", False), (32865, 1024, 1024, "vggt proj+res", True),
+              (L, 5120, 1152, "bicross out1+res", True), (32865, 1024, 1152, "bicross out2+res", True), (L, 2048, 2048, "adapter g1", False)]
+for (M, N, K, tag, res) in SHAPES:
     x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     lin = Linear(torch.randn(N, K, device="cuda", generator=g).to(torch.bfloat16) * K ** -0.5, torch.zeros(N, device="cuda"))
     if args.zeros:
