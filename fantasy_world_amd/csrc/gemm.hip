@@ -504,7 +504,7 @@ __device__ __forceinline__ void epilogue_w4(const GemmArgs& p, char* smem, f32x1
 // LDS-DMA issued from the LOAD phases instead of from inside the bursts (+-0), the slot barrier signalled one k-step early so its
 // release latency runs under the last MFMAs (+-0), a software L2 prefetch 3-4 slabs ahead (-10 %: the extra line requests cost
 // more than the misses they hide), a rotated K start per work-group against channel hot-spotting (-6 %: it breaks the lockstep L2
-// sharing of A bands / W panels), staggered work-group starts to de-phase the residual epilogues (-3..-20 %).  The TIMING build
+// sharing of A bands / W panels), staggered work-group starts to de-phase the residual epilogues (-3..-20 % before the epilogue rewrite; +-0.3 % after it, with the XCDs offset by 0.5 / 1 / 2 us in the first round: the residual epilogue is bound by one CU's loads in flight, not by the chip-wide burst).  The TIMING build
 // (TS, tools/gemm_timeline.py) stamps s_memtime at the phase boundaries.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ unsigned long long g_gemm_ts[2 * 64];     // TIMING build: [group][slab 0..3][phase 0..3][start | end of work]
