@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=832)
     ap.add_argument("--layers", type=int, default=40, help="debug only: anything but 40 is not a BASELINE workload")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="with --precision fp8: the DiT self-attention on e4m3 q / k / v / probabilities too (BASELINE configs[4]: "
+                         "'fp8 attention + FFN'; parity unpinned -- the reference defines no fp8 attention; never the headline)")
     ap.add_argument("--cache-invariants", action="store_true")
     ap.add_argument("--merge-cfg", action="store_true", help="N = 1: the two CFG forwards of a step as ONE pass over 2L rows")
     ap.add_argument("--experts", type=int, default=None, help="wan22: resident experts (default 2; 1 = high-noise only)")
@@ -175,7 +178,8 @@ def main():
     n_experts = (args.experts or 2) if wan22 else 1
     t0 = time.time()
     engines = [FusionEngine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s), ops, shard=shard,
-                            cache_step_invariants=args.cache_invariants, precision=args.precision) for s in range(n_experts)]
+                            cache_step_invariants=args.cache_invariants, precision=args.precision,
+                            fp8_attention=args.fp8_attention) for s in range(n_experts)]
     torch.cuda.synchronize()
     t_build = time.time() - t0
     eng = engines[0]
@@ -296,13 +300,15 @@ def main():
         "metric": metric,
         "value": value, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "fp8_e4m3 linears (fp32 accumulate), bf16 attention" if args.precision == "fp8" else "bf16", "data": "synthetic",
+        "dtype": ("fp8_e4m3 linears (fp32 accumulate), " + ("fp8_e4m3 DiT self-attention (fp32 scores / softmax / accumulate; parity unpinned)"
+                                                          if args.fp8_attention else "bf16 attention"))
+                 if args.precision == "fp8" else "bf16", "data": "synthetic",
         "config": {"workload": workload, "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,
                    "parallelism": topo.describe(), "step_invariant_cache": bool(args.cache_invariants),
                    "cfg_merged_in_one_pass": bool(args.merge_cfg and world == 1),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
-        "roofline": {"bound": "mfma", "kernel": "attention_sp_kernel<128, 1> (DiT self-attention, one launch per block"
+        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_pp_kernel" if args.fp8_attention else "attention_sp_kernel<128, 1>") + " (DiT self-attention, one launch per block"
                                + ("" if n_groups == 1 else f", in {n_groups} head groups under the sequence shard") + ")",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,

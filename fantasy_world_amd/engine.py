@@ -89,15 +89,23 @@ class FusionEngine:
     """Holds the pre-packed weights of one fusion model on one device and runs joint_forward on it."""
 
     def __init__(self, cfg: FWConfig, get: Callable[[str], torch.Tensor], ops, shard=None, heads_cfg=None,
-                 cache_step_invariants=False, precision="bf16"):
+                 cache_step_invariants=False, precision="bf16", fp8_attention=False):
         """`get(name)` returns the reference parameter `name` (any dtype/device); tensors are packed block by block
         so a 14B model never needs a second full-precision copy.  `shard` is an optional
         fantasy_world_amd.parallel.SequenceShard (one process per GPU, RCCL).  `heads_cfg` (config.HeadsConfig) enables the
         geometry heads: joint_forward(return_prediction=True) then returns the reference's prediction dict
         (vggt.py:134-154); their weights are packed on first use.  `cache_step_invariants` keeps the intermediates that
-        only depend on the prompt / camera inputs across calls (same results, bit for bit; see _InvariantCache)."""
+        only depend on the prompt / camera inputs across calls (same results, bit for bit; see _InvariantCache).
+        `precision="fp8"` routes the DiT blocks' linears through the reference's fp8 linear; `fp8_attention=True` additionally
+        runs the DiT self-attention (hd 128, 41 % of a step's FLOPs) on e4m3 q / k / v / probabilities (BASELINE config 5; parity
+        UNPINNED -- the reference defines no fp8 attention; single-GPU, not combined with a sequence shard)."""
         if precision not in ("bf16", "fp8"):
             raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
+        if fp8_attention and shard is not None:
+            raise ValueError("fp8_attention is not available under a sequence shard")
+        if fp8_attention and cfg.head_dim != 128:
+            raise ValueError("fp8_attention needs head_dim 128")
+        self.fp8_attention = bool(fp8_attention)
         self.cfg = cfg
         self.ops = ops
         self.shard = shard
@@ -269,7 +277,7 @@ class FusionEngine:
         tab = tabs["dit"] if sh is None else tabs["dit_local"]
         # softmax_scale * log2(e) is folded into q before its bf16 rounding: attention then works in the log2 domain
         ops.qk_prep(q, H, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
-                    out_scale=ops.q_scale(hd))
+                    out_scale=ops.q_scale_fp8(hd) if self.fp8_attention else ops.q_scale(hd))
         ops.qk_prep(k, H, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab)
         st.qkv = qkv
         st.exchange = sh is not None and sh.heads_divisible(H)
@@ -298,7 +306,13 @@ class FusionEngine:
         else:
             got = st.pend.wait()
             k, v = (st.qkv[:, D:2 * D], st.qkv[:, 2 * D:]) if got is None else (got[:, :D], got[:, D:])
-            st.pend = Ready(ops.attention(st.qkv[:, :D], k, v, H, hd, batch=self._nb, q_prescaled=True))
+            if self.fp8_attention:
+                # e4m3 q / k / v, fp32 scores and softmax, e4m3 probabilities (fw_attention_fp8; PARITY UNPINNED: the reference has
+                # no fp8 attention, include/fw_mi355x.h)
+                vt8, Lk = ops.prepare_v_fp8(v, H, hd, batch=self._nb)
+                st.pend = Ready(ops.attention_fp8(ops.cast_fp8(st.qkv[:, :D]), ops.cast_fp8(k), vt8, H, hd, Lk, batch=self._nb))
+            else:
+                st.pend = Ready(ops.attention(st.qkv[:, :D], k, v, H, hd, batch=self._nb, q_prescaled=True))
         st.qkv = None
 
     def _dit_attn_end(self, st, ctx_txt, ctx_img, plucker):

@@ -23,7 +23,7 @@ SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_attention_workspace_bytes", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
     "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_debug_gemm_timestamps", "fw_control_patchify", "fw_im2col3x3",
-    "fw_im2col", "fw_conv_gemm_bf16", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
+    "fw_im2col", "fw_conv_gemm_bf16", "fw_v_transpose_fp8", "fw_attention_fp8", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
     "fw_fp8_quant_rows", "fw_gemm_fp8",
@@ -67,6 +67,8 @@ def load_library(path: str = LIB_PATH):
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
         "fw_conv_gemm_bf16": [vp, i64] + [i32] * 14 + [vp, i64, vp, i64, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
+        "fw_v_transpose_fp8": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
+        "fw_attention_fp8": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp],
         "fw_softmax_rows": [vp, i64, vp, i64, i32, i32, i32, f32, vp],
         "fw_fp8_quant_rows": [vp, i64, vp, i64, vp, i32, i32, i32, vp],
         "fw_gemm_fp8": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
@@ -89,7 +91,7 @@ def load_library(path: str = LIB_PATH):
         fn.argtypes = args
     lib.fw_attention_workspace_bytes.restype = i64
     lib.fw_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    if lib.fw_abi_version() != 8:
+    if lib.fw_abi_version() != 9:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -587,6 +589,47 @@ class HipOps:
             _dt(out), M, lin.N, K, _ptr(lin.b), ACT[act], _ptr(g1), _ptr(g0),
             _ptr(res), 0 if res is None else res.stride(0), FW_DT_NONE if res is None else _dt(res),
             self._stream()), "fw_gemm_fp8")
+        self._time_end(tok)
+        return out
+
+    # ---- fp8 attention (hd 128; parity unpinned: no reference semantics, see include/fw_mi355x.h) ---------------------------
+    FP8_Q_EXP = 3      # Q8 holds q * softmax_scale * log2(e) * 2^3
+
+    def q_scale_fp8(self, hd):
+        """out_scale for qk_prep when q is to be cast to e4m3 for attention_fp8."""
+        return self.q_scale(hd) * float(2 ** self.FP8_Q_EXP)
+
+    def cast_fp8(self, x):
+        """bf16 [rows, C] (strided rows ok) -> e4m3 bytes, raw cast (round to nearest even, no scale)."""
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+        self._check_dev(x)
+        out = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        _check(self.lib.fw_fp8_quant_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), None, x.shape[0], x.shape[1], 1,
+                                          self._stream()), "fw_fp8_quant_rows")
+        return out
+
+    def prepare_v_fp8(self, v, heads, hd, batch=1):
+        assert v.dtype == torch.bfloat16 and v.stride(1) == 1
+        self._check_dev(v)
+        Lk = v.shape[0] // batch
+        lkp = (Lk + 63) // 64 * 64
+        vt = torch.empty(batch, heads, hd, lkp, dtype=torch.uint8, device=self.device)
+        _check(self.lib.fw_v_transpose_fp8(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk,
+                                           self._stream()), "fw_v_transpose_fp8")
+        return vt, Lk
+
+    def attention_fp8(self, q8, k8, vt8, heads, hd, Lk, batch=1, out=None):
+        """q8 / k8: e4m3 bytes [batch*L, heads*hd] (q pre-multiplied by q_scale_fp8(hd) before the cast), vt8 from prepare_v_fp8."""
+        assert q8.dtype == torch.uint8 and k8.dtype == torch.uint8 and q8.stride(1) == 1 and k8.stride(1) == 1
+        self._check_dev(q8, k8, vt8, out)
+        Lq = q8.shape[0] // batch
+        assert k8.shape[0] // batch == Lk
+        if out is None:
+            out = torch.empty(batch * Lq, heads * hd, dtype=torch.bfloat16, device=self.device)
+        tok = None if self._timing is None else self._time_begin(dict(kind="attention", hd=hd, Lq=Lq, Lk=Lk, heads=heads, batch=batch, fp8=True))
+        _check(self.lib.fw_attention_fp8(q8.data_ptr(), q8.stride(0), Lq * q8.stride(0), k8.data_ptr(), k8.stride(0), Lk * k8.stride(0),
+                                         vt8.data_ptr(), vt8.shape[-1], out.data_ptr(), out.stride(0), Lq * out.stride(0),
+                                         batch, heads, hd, Lq, Lk, self.FP8_Q_EXP, self._stream()), "fw_attention_fp8")
         self._time_end(tok)
         return out
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 8
+#define FW_ABI_VERSION 9
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -318,6 +318,24 @@ int fw_softmax_rows(const float* s, int64_t lds, uint16_t* out, int64_t ldo, int
  * raw = 1: q = e4m3(x), scale untouched                                                                  (weight cast, layers.py:137)
  * x bf16 [M][K] (ldx), q bytes [M][K] (ldq), round-to-nearest-even. */
 int fw_fp8_quant_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int M, int K, int raw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * fp8 attention (BASELINE.json configs[4]: "CDNA4 fp8 attention + FFN"), head_dim 128 = the DiT self-attention.
+ * PARITY UNPINNED: the reference has no fp8 attention (its fp8 entry is the nn.Linear swap above), so these semantics are this
+ * library's own: Q8 = e4m3(q * softmax_scale * log2(e) * 2^q_exp), K8 = e4m3(k) (both: fw_qk_prep, then fw_fp8_quant_rows with
+ * raw = 1), Vt8 = fw_v_transpose_fp8(v); scores in fp32 (scaled MFMA, the 2^q_exp undone by the operand's block scale), online
+ * softmax in fp32, P = e4m3(2^(s - m + 7)), O accumulated in fp32, written as bf16.  Opt-in (FusionEngine(fp8_attention=True)).
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* V [batch][Lk][heads*hd] bf16 (row stride ldv, batch stride bsv, elements) -> Vt8 [batch][heads][hd][lkp] e4m3 bytes,
+ * lkp % 64 == 0, keys >= Lk zero; inside each 64-key tile the keys sit in the order the PV operand of fw_attention_fp8 reads them. */
+int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads, int hd, int Lk,
+                       void* stream);
+
+/* O[b][q][h*128 + d] = softmax_k(Q K^T) V per (batch, head); strides of Q8 / K8 in BYTES (= elements), of O in bf16 elements. */
+int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, const uint8_t* K8, int64_t ldk, int64_t bsk,
+                     const uint8_t* Vt8, int64_t lkp, uint16_t* O, int64_t ldo, int64_t bso,
+                     int batch, int heads, int head_dim, int Lq, int Lk, int q_exp, void* stream);
 
 /* C[M][N] = epi((A[M][K] W[N][K]^T) * scale_a[m] + bias[n])  -- torch._scaled_mm(xq, wq^T, scale_a, 1, bias, out_dtype)
  * (layers.py:141-148), fp32 accumulation; A, W e4m3 bytes (K % 64 == 0), bias fp32 holding bf16-rounded values (or NULL).

@@ -104,3 +104,68 @@ def test_fp8_linear_against_bf16_linear(ops):
     err = rel_l2(b, a)
     print(f"fp8 vs bf16 linear rel-L2 {err:.3e}")
     assert err < 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# fp8 attention (fw_attention_fp8, hd 128).  PARITY UNPINNED: the reference defines no fp8 attention, so there is nothing of its to
+# pin against; what is held here is (1) the layout work, bit for bit (the V transpose / permutation / cast is a gather plus the same
+# round-to-nearest-even cast torch does), (2) the kernel against the fp32 softmax definition with an fp8-sized tolerance -- e4m3 has
+# a 3-bit mantissa: q, k, v and the probabilities each carry ~2 % relative noise, which measures 5e-2 rel-L2 on random data
+# (bound 8e-2, tightened to 1.5 x measured by the parity log) -- and (3) the two kernel generations against each other.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, B, H, hd):
+    import math
+    Lq, Lk = q.shape[0] // B, k.shape[0] // B
+    qf, kf, vf = (t.float().view(B, -1, H, hd).permute(0, 2, 1, 3) for t in (q, k, v))
+    o = torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(hd), -1) @ vf
+    return o.permute(0, 2, 1, 3).reshape(B * Lq, H * hd)
+
+
+def test_v_transpose_fp8_is_an_exact_gather_and_cast(ops):
+    B, H, hd, Lk = 2, 3, 128, 150
+    v = rnd(B * Lk, H * hd, seed=71, scale=3.0).to(torch.bfloat16)
+    vt, lk = ops.prepare_v_fp8(v.cuda(), H, hd, batch=B)
+    assert lk == Lk and vt.shape == (B, H, hd, 192) and vt.dtype == torch.uint8
+    want8 = v.float().to(torch.float8_e4m3fn).view(torch.uint8).view(B, Lk, H, hd).permute(0, 2, 3, 1)      # [B, H, hd, Lk]
+    pad = torch.zeros(B, H, hd, 192, dtype=torch.uint8)
+    pad[..., :Lk] = want8
+    # position p of a 64-key tile holds key kappa(p): p = hi*32 + block*16 + r  <->  kappa = block*32 + (r&3) + 8*(r>>2) + 4*hi
+    pos = torch.arange(64)
+    hi, blk, r = pos >> 5, (pos >> 4) & 1, pos & 15
+    kappa = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
+    want = pad.view(B, H, hd, 3, 64)[..., kappa].reshape(B, H, hd, 192)
+    assert torch.equal(vt.cpu(), want)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 4, 300, 200), (1, 2, 256, 64), (2, 3, 515, 1029), (1, 4, 1024, 4096), (1, 1, 31, 7)])
+def test_attention_fp8_against_fp32_softmax(ops, B, H, Lq, Lk, parity, request):
+    hd = 128
+    q, k, v = (rnd(B * n, H * hd, seed=s).to(torch.bfloat16).cuda() for n, s in ((Lq, 72), (Lk, 73), (Lk, 74)))
+    want = _attn_ref(q.cpu(), k.cpu(), v.cpu(), B, H, hd)
+    q8 = ops.cast_fp8(ops.qk_prep(q.clone(), H, hd, out_scale=ops.q_scale_fp8(hd)))
+    vt8, _ = ops.prepare_v_fp8(v, H, hd, batch=B)
+    outs = {}
+    try:
+        for var in (192, 8):                                   # default = two-group ping-pong kernel; 8 = the in-phase kernel
+            ops.set_option("attn_var", var)
+            outs[var] = ops.attention_fp8(q8, ops.cast_fp8(k), vt8, H, hd, Lk, batch=B).float().cpu()
+    finally:
+        ops.set_option("attn_var", 192)
+    assert torch.isfinite(outs[192]).all()
+    parity.check(f"op/{request.node.name}/vs_fp32_softmax", rel_l2(outs[192], want), 8e-2)
+    parity.check(f"op/{request.node.name}/pingpong_vs_inphase_kernel", rel_l2(outs[192], outs[8]), 1e-3)
+
+
+def test_attention_fp8_score_spike_and_late_maximum(ops, parity, request):
+    """The softmax shift is set by the first tile and only moves when a later score would overflow e4m3: a row whose largest score
+    sits in the LAST tile (and 40 units above the first tile's) must come out right."""
+    H, hd, Lq, Lk = 2, 128, 256, 1024
+    q, k, v = (rnd(n, H * hd, seed=s).to(torch.bfloat16) for n, s in ((Lq, 75), (Lk, 76), (Lk, 77)))
+    k[-3] = (q[5].float() * 4.0).to(torch.bfloat16)           # key 1021 aligned with query 5 (both heads): a late, dominant score
+    want = _attn_ref(q, k, v, 1, H, hd)
+    q8 = ops.cast_fp8(ops.qk_prep(q.cuda().clone(), H, hd, out_scale=ops.q_scale_fp8(hd)))
+    vt8, _ = ops.prepare_v_fp8(v.cuda(), H, hd)
+    got = ops.attention_fp8(q8, ops.cast_fp8(k.cuda()), vt8, H, hd, Lk).float().cpu()
+    assert torch.isfinite(got).all()
+    parity.check(f"op/{request.node.name}/all_rows", rel_l2(got, want), 8e-2)
+    parity.check(f"op/{request.node.name}/spiked_row", rel_l2(got[5], want[5]), 8e-2)

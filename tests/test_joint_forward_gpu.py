@@ -325,6 +325,27 @@ def test_hip_sequence_shard_over_rccl_single_rank_group(case_l3):
             dist.destroy_process_group()
 
 
+def test_hip_fp8_attention_engine_is_close_to_the_bf16_engine(case_cfg1, parity):
+    """FusionEngine(precision="fp8", fp8_attention=True): BASELINE config 5's arithmetic (fp8 linears + fp8 DiT self-attention) at
+    config-1 size.  PARITY UNPINNED for the attention part (no reference semantics): the check is a stated distance to the bf16
+    engine and to the reference golden -- fp8 noise (3-bit mantissas on q / k / v / probabilities) through 2 blocks."""
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    case = case_cfg1
+    ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
+    kw = forward_kwargs(case, "cuda")
+    outs = {}
+    for tag, opts in (("bf16", {}), ("fp8_linears", dict(precision="fp8")), ("fp8_all", dict(precision="fp8", fp8_attention=True))):
+        eng = FusionEngine(case.cfg, case.weights.__getitem__, HipOps("cuda:0"), **opts)
+        outs[tag], _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+        del eng
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs["fp8_all"].float()).all()
+    parity.check("fp8attn/cfg1/vs_bf16_engine", rel_l2(outs["fp8_all"].float(), outs["bf16"].float()), 1e-1)
+    parity.check("fp8attn/cfg1/vs_fp8_linears_engine", rel_l2(outs["fp8_all"].float(), outs["fp8_linears"].float()), 1e-1)
+    parity.check("fp8attn/cfg1/vs_reference_golden", rel_l2(outs["fp8_all"].float(), case.golden["noise_pred"]), 1e-1)
+
+
 class _ThreadComm:
     """In-process rendezvous of `world` rank threads that share ONE GPU (and its default stream, so enqueue order = execution
     order: what a rank deposited before the barrier is complete before anything a peer enqueues after it)."""
