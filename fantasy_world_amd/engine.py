@@ -105,6 +105,8 @@ class FusionEngine:
             raise ValueError("fp8_attention is not available under a sequence shard")
         if fp8_attention and cfg.head_dim != 128:
             raise ValueError("fp8_attention needs head_dim 128")
+        if fp8_attention and not hasattr(ops, "attention_fp8"):
+            raise ValueError("fp8_attention needs the HIP op set (fw_attention_fp8); it has no CPU statement")
         self.fp8_attention = bool(fp8_attention)
         self.cfg = cfg
         self.ops = ops

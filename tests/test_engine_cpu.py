@@ -247,3 +247,16 @@ def test_merged_cfg_pair_equals_two_forwards(case_name, request):
     a, _ = denoise_step(eng, sched, 3, ins["x"], ins["context"], ins["context_neg"], cond)
     b, _ = denoise_step(eng, sched, 3, ins["x"], ins["context"], ins["context_neg"], cond, merge_cfg=True)
     assert rel_l2(b, a) < 1e-6
+
+
+def test_fp8_attention_option_is_hip_only(case_l2):
+    """fp8 attention has no reference semantics and no CPU statement: asking for it on the torch op set (or under a sequence shard)
+    must fail at construction, not somewhere inside the first forward."""
+    import pytest
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.parallel import SequenceShard
+    from oracle.ref_ops import TorchRefOps
+    with pytest.raises(ValueError, match="HIP op set"):
+        FusionEngine(case_l2.cfg, case_l2.weights.__getitem__, TorchRefOps(), precision="fp8", fp8_attention=True)
+    with pytest.raises(ValueError, match="sequence shard"):
+        FusionEngine(case_l2.cfg, case_l2.weights.__getitem__, TorchRefOps(), shard=SequenceShard(0, 2), fp8_attention=True)
