@@ -41,6 +41,7 @@ struct GemmArgs {
     const float* bias; int act; const float* g1; const float* g0;
     const void* res; int64_t ldr; int res_dtype;
     int tiles_m, tiles_n;
+    int group_m;                         // M-tiles per group of the tile order of the ping-pong kernel
     ConvGeom cv;                         // read by the CONV instantiations only
 };
 
@@ -534,10 +535,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     }
     int tm, tn;
     {
-        const int per_group = GROUP_M * p.tiles_n;
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
         const int gid = wg / per_group;
-        const int first_m = gid * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int first_m = gid * GM;
+        const int gsz = min(p.tiles_m - first_m, GM);
         const int in_g = wg - gid * per_group;
         tm = first_m + in_g % gsz;
         tn = in_g / gsz;
@@ -887,6 +889,11 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.out_dtype = out_dtype;
     p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.g1 = g1; p.g0 = g0;
     p.res = res; p.ldr = ldr; p.res_dtype = res ? res_dtype : FW_DT_NONE;
+    // M-tiles per group of the ping-pong kernel's tile order (FW_GEMM_VAR >> 4 overrides, A/B).  Interleaved A/B on the forward's
+    // shapes (tools/gemm_ab.py, profiles/r02/gemm_experiments.md): 4 against 8 is +1.6 % on the N = 5120 gate + residual GEMMs,
+    // +6.8 % on the bicross output projection, +-0 on qkv / ffn0, and -2..3 % on the narrow VGGT outputs (N = 3072 / 4096); 2, 3, 5, 6
+    // lose to 4 and 16 / 32 lose 10-15 %.
+    p.group_m = (fw_get_option(FW_OPT_GEMM_VAR) >> 4) ? (fw_get_option(FW_OPT_GEMM_VAR) >> 4) : ((N + TN - 1) / TN >= 20 ? 4 : GROUP_M);
     // tile choice: the 256x256 staggered kernel for the big token-major GEMMs, 128x128 otherwise.
     // FW_GEMM_TILE=128|256 forces one (A/B measurements).
     const int forced = fw_get_option(FW_OPT_GEMM_TILE);
@@ -972,6 +979,7 @@ extern "C" int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, i
     p.A = x; p.lda = ldx; p.W = Wt; p.ldw = ldw; p.C = Cout; p.ldc = ldc; p.out_dtype = out_dtype;
     p.M = (int)M64; p.N = N; p.K = (int)K64; p.bias = bias; p.act = act; p.g1 = g1; p.g0 = g0;
     p.res = res; p.ldr = ldr; p.res_dtype = res ? res_dtype : FW_DT_NONE;
+    p.group_m = GROUP_M;
     p.cv.T = T; p.cv.H = H; p.cv.W = W; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.kt = kt; p.cv.kh = kh; p.cv.kw = kw;
     p.cv.sh = sh; p.cv.sw = sw; p.cv.ph = ph; p.cv.pw = pw; p.cv.ups = up == 2 ? 1 : 0; p.cv.t0 = t0; p.cv.cpt = C / BK;
     const int M = p.M, K = p.K;
