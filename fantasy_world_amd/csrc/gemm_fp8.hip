@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
     }
     int tm, tn;
     {
-        constexpr int GROUP = 8;
+        const int GROUP = p.tiles_n >= 20 ? 4 : 8;      // the bf16 kernel's measurement (gemm.hip: 4 M-tiles per group for wide outputs)
         const int per_group = GROUP * p.tiles_n;
         const int gid = wg / per_group;
         const int first_m = gid * GROUP;
