@@ -92,9 +92,13 @@ template <int ACT> __device__ __forceinline__ float fw_apply_act_ct(float v) {
     return v;
 }
 
-template <bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+// NST = 2: two 32 KiB stages, two work-groups per CU -- grids of many tiles.  NST = 4: a 4-deep ring with counted waits (three slabs
+// in flight) and the CU to itself -- the launches with at most one round of tiles (the <= 128-row M tails of the VGGT / bicross
+// GEMMs, context K/V, embeddings), where a work-group walks K alone and the 2-stage loop pays a DMA round trip per slab.  Same k
+// order per output element either way (bit-identical results).
+template <bool CONV, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[NST * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -178,11 +182,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = p.K / BK;
-    stage(0);
-    __syncthreads();
+    if (NST == 2) {
+        stage(0);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; ++s0)
+            if (s0 < nk) stage(s0);
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1);
-        const char* base = smem + (kt & 1) * STAGE_BYTES;
+        if (NST == 2) {
+            if (kt + 1 < nk) stage((kt + 1) & 1);
+        } else {
+            // slab kt has landed once at most the NST - 2 slabs requested after it are still in flight (8 DMA pieces per wave and slab)
+            if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NST - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // visible to all; everyone is done reading slab kt - 1
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NST - 1 < nk) stage((kt + NST - 1) % NST);
+        }
+        const char* base = smem + (kt % NST) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8_t a0 = *(const bf16x8_t*)(base + a_row_off + coff[ks]);
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        __syncthreads();   // next slab landed (vmcnt(0)) and every wave is done reading this one
+        if (NST == 2) __syncthreads();   // next slab landed (vmcnt(0)) and every wave is done reading this one
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------
@@ -926,7 +946,7 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
             t.res = res ? (const char*)res + (size_t)Mfull * ldr * rbytes : nullptr;
             t.M = tail;
             t.tiles_m = 1; t.tiles_n = (N + BN - 1) / BN;
-            hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3((unsigned)t.tiles_n), dim3(256), 0, (hipStream_t)stream, t);
+            hipLaunchKernelGGL((gemm_bf16_kernel<false, 4>), dim3((unsigned)t.tiles_n), dim3(256), 0, (hipStream_t)stream, t);      // one row of tiles: deep ring
             return (int)hipGetLastError();
         }
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
@@ -950,7 +970,8 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_bf16: grid too large"); return FW_E_BADARG; }
-    hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    if (nwg <= 256) hipLaunchKernelGGL((gemm_bf16_kernel<false, 4>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, 2>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1001,7 +1022,7 @@ extern "C" int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, i
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     const int64_t nwg = (int64_t)p.tiles_m * p.tiles_n;
     if (nwg > 0x7fffffff) { fw_set_error("fw_conv_gemm_bf16: grid too large"); return FW_E_BADARG; }
-    hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, 2>), dim3((unsigned)nwg), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 
