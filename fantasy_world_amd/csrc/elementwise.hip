@@ -81,6 +81,26 @@ __global__ __launch_bounds__(256) void layernorm_mod_kernel(const void* __restri
 // ------------------------------------------------------------------------------------------------------------
 constexpr int LNW_MAXV = 20;
 
+// The normalise / modulate arithmetic of BOTH LayerNorm wave kernels, spelled out operation by operation (no contraction, no
+// reassociation): u = (v - mean) * rstd;  [u = u * w (+ b)];  u = fma(u, scale, u) = u * (1 + scale) in one rounding;  u = u + shift.
+// A sequence shard (few rows per rank: one-wave-per-row kernel) and the unsharded forward (LDS-staged kernel) must agree bit for bit.
+__device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, const float* w, const float* b, bool has_scale,
+                                             f32x4_t sc, bool has_shift, f32x4_t sh, int c0) {
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
+    f32x4_t t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u = v[j] - mean;
+        u = u * rstd;
+        if (w) { u = u * w[c0 + j]; if (b) u = u + b[c0 + j]; }
+        if (has_scale) u = __builtin_fmaf(u, sc[j], u);
+        if (has_shift) u = u + sh[j];
+        t[j] = u;
+    }
+    return t;
+}
+
 template <bool XF32, int VPL>
 __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __restrict__ xin, int64_t ldx,
                                                                  uint16_t* __restrict__ y, int64_t ldy, int rows, int C,
@@ -118,18 +138,64 @@ __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __r
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c0 = (lane + 64 * i) * 4;
-        f32x4_t t = (v[i] - mean) * rstd;
-        if (w) { t = t * *(const f32x4_t*)(w + c0); if (b) t = t + *(const f32x4_t*)(b + c0); }
-        if (scale) t = t * (1.0f + *(const f32x4_t*)(scale + c0));
-        if (shift) t = t + *(const f32x4_t*)(shift + c0);
+        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t t = ln_finish(v[i], mean, rstd, w, b, scale != nullptr, scale ? *(const f32x4_t*)(scale + c0) : zero,
+                                    shift != nullptr, shift ? *(const f32x4_t*)(shift + c0) : zero, c0);
         u32x2_t out = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
         *(u32x2_t*)(yr + c0) = out;
+    }
+}
+
+// The hot case -- AdaLN-modulated LayerNorm of the fp32 DiT stream, no affine weights (wan_video_dit.py:301-310; 290 launches per
+// step) -- with the two modulation vectors staged ONCE per work-group in LDS and the work-groups walking the rows: the kernel above
+// re-reads 40 KiB of scale / shift through the texture path for every 20 KiB row it normalises (60 vector loads per row instead of
+// 20), and measures 4.7 TB/s where torch's plain fp32 -> bf16 cast reaches 5.85 (tools/probes/stream_bw.py).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_mod_lds_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
+                                                                int64_t ldy, int rows, int C, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float eps) {
+    __shared__ f32x4_t smA[VPL * 64], smB[VPL * 64];          // scale, shift
+    for (int i = threadIdx.x; i < VPL * 64; i += 256) {
+        smA[i] = *(const f32x4_t*)(scale + i * 4);
+        smB[i] = *(const f32x4_t*)(shift + i * 4);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        f32x4_t v[VPL];
+        const float* xr = x + (int64_t)row * ldx;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = *(const f32x4_t*)(xr + (lane + 64 * i) * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        uint16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            const f32x4_t t = ln_finish(v[i], mean, rstd, nullptr, nullptr, true, smA[c], true, smB[c], c * 4);
+            u32x2_t out = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
+            *(u32x2_t*)(yr + c * 4) = out;
+        }
     }
 }
 
 template <bool XF32>
 static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C,
                            const float* w, const float* b, const float* scale, const float* shift, float eps) {
+    if (XF32 && C == 5120 && !w && !b && scale && shift && rows >= 4096) {
+        // 4 work-groups of 40 KiB LDS per CU, each walking rows
+        const int wgs = min((rows + 3) / 4, 256 * 4);
+        hipLaunchKernelGGL(layernorm_mod_lds_kernel<20>, dim3(wgs), dim3(256), 0, st, (const float*)x, ldx, y, ldy, rows, C, scale, shift, eps);
+        return true;
+    }
     const dim3 grid((rows + 3) / 4), block(256);
 #define FW_LN_CASE(V) case V: hipLaunchKernelGGL((layernorm_mod_wave_kernel<XF32, V>), grid, block, 0, st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps); return true;
     switch (C / 256) {

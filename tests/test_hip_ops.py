@@ -342,6 +342,23 @@ def test_layernorm_mod(ops, ref, C, rows, affine, mod, xdt, parity, request):
     parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
+def test_layernorm_mod_large_row_kernel_is_bit_identical_to_the_small_one(ops, ref, parity, request):
+    """From 4096 rows on, the modulated LayerNorm of the fp32 DiT stream (C = 5120, no affine weights) runs on the kernel that stages
+    1 + scale / shift in LDS and walks the rows; below, on the one-wave-per-row kernel.  Same arithmetic in the same order: a call over
+    4100 rows equals the concatenation of two calls over 2050 rows BIT FOR BIT (a sequence shard sees the small kernel, the unsharded
+    forward the large one), and both match the fp32 definition."""
+    C, rows = 5120, 4100
+    x = torch.randn(rows, C, generator=torch.Generator().manual_seed(51))
+    sc, sh = rnd(C, seed=52, scale=0.3), rnd(C, seed=53, scale=0.3)
+    want = ref.layernorm(x, scale=sc, shift=sh, eps=1e-6)
+    xd, scd, shd = x.cuda(), sc.cuda(), sh.cuda()
+    big = ops.layernorm(xd, scale=scd, shift=shd, eps=1e-6)
+    halves = torch.cat([ops.layernorm(xd[:2050].contiguous(), scale=scd, shift=shd, eps=1e-6),
+                        ops.layernorm(xd[2050:].contiguous(), scale=scd, shift=shd, eps=1e-6)], dim=0)
+    assert torch.equal(big, halves)
+    parity.check(f"op/{request.node.name}/0", rel_l2(big.float(), want), 4e-3)
+
+
 def test_qk_prep_rms_full_rope3d(ops, ref, parity, request):
     """DiT q/k: RMSNorm over the full 5120 width (DIT21:170-171) + interleaved 3-D RoPE (DIT21:97-102)."""
     from fantasy_world_amd import rope
