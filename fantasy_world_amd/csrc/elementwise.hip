@@ -358,10 +358,18 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
                                                            const float* __restrict__ nw, const float* __restrict__ nb, float eps,
                                                            const float* __restrict__ tab, int tab_rows, float oscale) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int width = heads * hd;
     const int nch = width >> 3;
+    // Full-width RMSNorm (the DiT q / k: 5120 weights = 20 KiB for every 10 KiB row): the weight vector is staged ONCE per work-group
+    // in LDS and the work-groups walk the rows (the launcher caps the grid), instead of re-reading it through the texture path per
+    // row -- the LayerNorm kernel's finding (tools/probes/stream_bw.py).  Other modes: one row per wave, the loop runs once.
+    constexpr bool STAGE = NORM == FW_NORM_RMS_FULL;
+    __shared__ f32x4_t snw[STAGE ? CPL * 128 : 1];
+    if (STAGE) {
+        for (int i = threadIdx.x; i < nch * 2; i += 256) snw[i] = *(const f32x4_t*)(nw + i * 4);
+        __syncthreads();
+    }
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
     uint16_t* xr = x + (int64_t)row * ldx;
     float v[CPL][8];
     u32x4_t raw[CPL];
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
         for (int i = 0; i < CPL; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                const f32x4_t w0 = *(const f32x4_t*)(nw + ch * 8), w1 = *(const f32x4_t*)(nw + ch * 8 + 4);
+                const f32x4_t w0 = snw[STAGE ? ch * 2 : 0], w1 = snw[STAGE ? ch * 2 + 1 : 0];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { v[i][j] = v[i][j] * r * w0[j]; v[i][4 + j] = v[i][4 + j] * r * w1[j]; }
             }
@@ -424,7 +432,16 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] *= oscale;
     }
-    const float* trow = (ROPE != FW_ROPE_NONE) ? tab + (int64_t)(row % tab_rows) * hd : nullptr;   // [hd/2][2]
+    // the row's rotary table ([hd/2][2] fp32 = 512 B at hd 128) is shared by every head of the row: one 8-byte load per lane puts it
+    // into a per-wave LDS strip, and the 20 lookups per lane go to LDS instead of through the texture path
+    __shared__ float strow[4][128];
+    const float* trow = nullptr;
+    if (ROPE != FW_ROPE_NONE) {
+        const float* grow = tab + (int64_t)(row % tab_rows) * hd;   // [hd/2][2]
+        float* mine = strow[threadIdx.x >> 6];
+        if (lane * 2 < hd) *(u32x2_t*)(mine + lane * 2) = *(const u32x2_t*)(grow + lane * 2);
+        trow = mine;
+    }
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int ch = lane + 64 * i;
@@ -459,12 +476,14 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             *(u32x4_t*)(xr + ch * 8) = o4;
         }
     }
+    }       // row loop
 }
 
 template <int CPL>
 static bool launch_qk_wave(hipStream_t st, uint16_t* x, int64_t ldx, int rows, int heads, int hd, int norm, const float* nw,
                            const float* nb, float eps, int rope, const float* tab, int tab_rows, float oscale) {
-    const dim3 grid((rows + 3) / 4), block(256);
+    // RMS_FULL stages 20 KiB of weights per work-group and walks the rows: 4 work-groups per CU; the other modes: one row per wave
+    const dim3 grid(norm == FW_NORM_RMS_FULL ? min((rows + 3) / 4, 256 * 4) : (rows + 3) / 4), block(256);
 #define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale); return true; }
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_INTERLEAVED)
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_NONE)

@@ -19,5 +19,10 @@ def t(fn, n=20):
     return a.elapsed_time(b) / n
 tc = t(lambda: y.copy_(x)); tb = t(lambda: z.copy_(y)); tl = t(lambda: ops.layernorm(x, scale=sc, shift=sh, eps=1e-6, out=y))
 tq = t(lambda: ops.qk_prep(y, 40, 128, out_scale=0.5))
+from fantasy_world_amd import rope as _rope
+tab = ops.to_f32(_rope.rope3d_table(128, 21, 30, 52))
+nw = torch.randn(D, device="cuda")
+tqr = t(lambda: ops.qk_prep(y, 40, 128, norm="rms_full", norm_w=nw, eps=1e-6, rope="interleaved", table=tab, out_scale=0.5))
+print(f"fw_qk_prep (full-width RMSNorm + RoPE-3D, the DiT q / k): {tqr*1e3:.0f} us = {L*D*4/tqr/1e9:.2f} TB/s")
 print(f"torch fp32->bf16 cast: {tc*1e3:.0f} us = {L*D*6/tc/1e9:.2f} TB/s | torch bf16 copy: {tb*1e3:.0f} us = {L*D*4/tb/1e9:.2f} TB/s | "
       f"fw_layernorm_mod: {tl*1e3:.0f} us = {L*D*6/tl/1e9:.2f} TB/s | fw_qk_prep (in place, scale only): {tq*1e3:.0f} us = {L*D*4/tq/1e9:.2f} TB/s")
