@@ -63,12 +63,14 @@ int fw_abi_version(void);
 #define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 4 (default) = 8-wave ping-pong kernel;
                                   5 = four-wave 128x128-wave-tile kernel for every big GEMM (independent implementation, A/B) */
 #define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: 0 (default); bit 1 = TIMING build of the ping-pong kernel (phase + tile stamps),
-                                  bit 2 = tile stamps only (tools/gemm_timeline.py) */
+                                  bit 2 = tile stamps only (tools/gemm_timeline.py); value >> 4 (if non-zero) = M-tiles per group of
+                                  the tile order (default 4 for outputs >= 20 column tiles wide, else 8; tools/gemm_ab.py) */
 #define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
                                    already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): single-stream kernel (129) for hd
                                    128 / 64, two-segment ping-pong (64) for hd 96.  131 = single-stream with one 64-row wave per
                                    SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
-                                   WITHOUT the pre-scaled flag get) */
+                                   WITHOUT the pre-scaled flag get).  fw_attention_fp8: 8 = its in-phase kernel, anything else =
+                                   its two-group ping-pong kernel */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
 
