@@ -121,25 +121,7 @@ class FusionEngine:
         self._tables = {}
         self._plucker_zero_cache = None
         self._nb, self._ctx_sources, self._img_sources = 1, (), ()
-        ops_ = ops
-        g = lambda n: get(n).detach().to(torch.float32)
-
-        def lin(wname, bname=None, k_pad=None, n_pad=None, fp8=False):
-            w = g(wname)
-            w = w.reshape(w.shape[0], -1)
-            b = g(bname) if bname else None
-            if k_pad:
-                w = _pad_to(w, 1, k_pad)
-            if n_pad:
-                w = _pad_to(w, 0, n_pad)
-                if b is not None:
-                    b = _pad_to(b, 0, n_pad)
-            return ops_.pack_linear(w, b, fp8=True) if fp8 else ops_.pack_linear(w, b)
-
-        def lin_cat(names, fp8=False):
-            w = torch.cat([g(n + ".weight") for n in names], dim=0)
-            b = torch.cat([g(n + ".bias") for n in names], dim=0)
-            return ops_.pack_linear(w, b, fp8=True) if fp8 else ops_.pack_linear(w, b)
+        g, lin, lin_cat = self._packers(get)
 
         pd = "pipe.dit."
         self.kpatch = _ru64(cfg.in_dim * 4)
@@ -179,9 +161,34 @@ class FusionEngine:
                         for j in range(len(cfg.cross_attention_list))]
 
     # ------------------------------------------------------------------------------------------------ packing
-    def _pack_dit(self, b, g, lin, lin_cat):
+    def _packers(self, get):
+        """(g, lin, lin_cat): fetch a reference parameter as fp32 / pack one nn.Linear / pack several as one fused projection."""
+        ops_ = self.ops
+        g = lambda n: get(n).detach().to(torch.float32)
+
+        def lin(wname, bname=None, k_pad=None, n_pad=None, fp8=False):
+            w = g(wname)
+            w = w.reshape(w.shape[0], -1)
+            b = g(bname) if bname else None
+            if k_pad:
+                w = _pad_to(w, 1, k_pad)
+            if n_pad:
+                w = _pad_to(w, 0, n_pad)
+                if b is not None:
+                    b = _pad_to(b, 0, n_pad)
+            return ops_.pack_linear(w, b, fp8=True) if fp8 else ops_.pack_linear(w, b)
+
+        def lin_cat(names, fp8=False):
+            w = torch.cat([g(n + ".weight") for n in names], dim=0)
+            b = torch.cat([g(n + ".bias") for n in names], dim=0)
+            return ops_.pack_linear(w, b, fp8=True) if fp8 else ops_.pack_linear(w, b)
+
+        return g, lin, lin_cat
+
+    def _pack_dit(self, b, g, lin, lin_cat, prefix=None, adapter=None):
+        """prefix / adapter given: a stand-alone block (fantasy_world_amd.blocks, boundary B2) instead of block b of the model."""
         cfg, ops = self.cfg, self.ops
-        p = cfg.dit_prefix(b)
+        p = cfg.dit_prefix(b) if prefix is None else prefix
         blk = _DitBlock()
         blk.index = b
         blk.mod = ops.to_f32(g(p + "modulation").reshape(6, cfg.dim))
@@ -202,7 +209,7 @@ class FusionEngine:
         if cfg.has_image_input:
             blk.ckv_img = lin_cat([p + "cross_attn.k_img", p + "cross_attn.v_img"], fp8=f8)
             blk.cnorm_k_img = ops.to_f32(g(p + "cross_attn.norm_k_img.weight"))
-        blk.adapter = cfg.has_adapter(b)
+        blk.adapter = cfg.has_adapter(b) if adapter is None else bool(adapter)
         if blk.adapter:
             a = p + "cross_attn.processor."
             rp = _ru64(cfg.adapter_reduced)

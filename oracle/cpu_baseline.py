@@ -6,11 +6,11 @@ timed at the workload's token counts and the step is assembled as
 
     t_step = 2 (CFG) x [ 16 t_PCB + 24 (t_frame + t_DiT + t_global + t_bicross) ]        (16 PCB blocks, 24 IRG iterations)
 
-  kind = "reference": the reference's OWN modules imported from /root/reference (DiTBlock wan_video_dit.py:254-321, VGGT Block
-         vggt/layers/block.py:22-116, CrossModalityBiAttentionBlock fusion/layer/block.py:146-221), default-initialised, fp32 --
-         only where the reference tree is mounted (the build container);
+  kind = "reference": the reference's OWN modules (DiTBlock wan_video_dit.py:254-321, VGGT Block vggt/layers/block.py:22-116,
+         CrossModalityBiAttentionBlock fusion/layer/block.py:146-221), default-initialised, fp32 -- wherever oracle/ref_locate.py
+         finds the reference: /root/reference in the build container, the staged bundle oracle/_ref/reference_py.tgz on the GPU box;
   kind = "port": oracle/fw_oracle.py's restatement of the same blocks (pinned to the reference by tests/test_oracle_pin.py) --
-         on the GPU box, where /root/reference does not exist.
+         only when neither is present.
 
 Thread count: swept over {8, 16, 32, 64, nproc} on a 2048-token DiT block (oversubscribing a big host is several times slower
 than 8-16 threads), the best one is used and reported.  Token counts: the full workload when the projected time fits
@@ -135,8 +135,9 @@ def _timed(fn):
 
 def measure(cfg, F, h, w, budget_s=60.0, reference_root=None):
     """-> dict for bench.py's `cpu_baseline` (value in denoise-steps/s) plus the raw timings (profiles/rNN/cpu_baseline.json)."""
-    root = reference_root or os.environ.get("FW_REFERENCE_ROOT", "/root/reference")
-    blocks = _ReferenceBlocks(cfg) if os.path.isdir(os.path.join(root, "FantasyWorld")) else _PortBlocks(cfg)
+    from oracle import ref_locate
+    root = reference_root or ref_locate.reference_root()
+    blocks = _ReferenceBlocks(cfg) if root and os.path.isdir(os.path.join(root, "FantasyWorld")) else _PortBlocks(cfg)
     Lc = 512 + (cfg.clip_tokens if cfg.has_image_input else 0)
     ncpu = os.cpu_count() or 1
     hw = h * w

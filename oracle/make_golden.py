@@ -240,6 +240,13 @@ SIZED_CASES = {
     # depth: 4 PCB + 4 IRG blocks on 96 tokens; the streams after EVERY block are stored, so the error growth with depth of
     # the bf16 path against the fp32 reference is measured, not inferred
     "wan21_depth_l8_s4_f2_12x16": (dict(num_layers=8, start_index=4), (2, 12, 16), 750.0, 512, 24, True),
+    # BASELINE.json configs[1] / [2] token grid (81f x 480 x 832 -> latents [1,16,21,60,104], L = 32760, L2 = 32865) on the 2-block
+    # model: the headline SIZE pinned to the real reference (round 3; the reference forward is a few CPU-minutes).  Timestep =
+    # the second one of the 50-step schedule (995.9 -> bf16 996).
+    "wan21_cfg2_l2_f21_60x104": (dict(num_layers=2, start_index=1), (21, 60, 104), 996.0, 512, 64, False),
+    # BASELINE.json configs[3] token grid (Wan2.2-Fun-A14B-Control-Camera, 81f x 720p -> latents [1,16,21,90,160], L = 75600,
+    # L2 = 75705), control adapter at its real size
+    "wan22_cfg4_l2_f21_90x160": (dict(num_layers=2, start_index=1), (21, 90, 160), 996.0, 512, 64, False),
 }
 
 
@@ -252,10 +259,11 @@ def main_sized(only):
     for name, (ckw, (f, h2, w2), ts, tl, nrows, per_block) in SIZED_CASES.items():
         if only and name not in only:
             continue
-        cfg = fwc.plumbing(**ckw)
+        wan22 = name.startswith("wan22")
+        cfg = (fwc.plumbing22 if wan22 else fwc.plumbing)(**ckw)
         W = synth.make_weights(cfg)
         ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=ts, text_len=tl)
-        model = ref_harness.build_reference_wan21(cfg, weights=W)
+        model = (ref_harness.build_reference_wan22 if wan22 else ref_harness.build_reference_wan21)(cfg, weights=W)
         assert not model._fw_unused
         L = f * (h2 // 2) * (w2 // 2)
         L2 = f * (cfg.n_special + (h2 // 2) * (w2 // 2))
@@ -271,17 +279,24 @@ def main_sized(only):
             model.IRGBlock[j].register_forward_hook(hook)
         t0 = time.time()
         with torch.no_grad():
-            out, pred = model.joint_forward(
-                ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"],
-                y=ins["y"], use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
-                plucker_context_lens=ins["plucker_context_lens"], uncond=False, return_prediction=False)
+            if wan22:       # model_wan22.py:231-242 signature
+                out, pred = model.joint_forward(
+                    ins["x"], timestep=ins["timestep"], context=ins["context"], y=ins["y"], use_gradient_checkpointing=False,
+                    camera_token=None, control_camera_latents_input=ins["control_camera_latents_input"], uncond=False,
+                    return_prediction=False)
+            else:
+                out, pred = model.joint_forward(
+                    ins["x"], timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"],
+                    y=ins["y"], use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+                    plucker_context_lens=ins["plucker_context_lens"], uncond=False, return_prediction=False)
         t_ref = time.time() - t0
         print(f"[{name}] reference forward {t_ref:.1f}s (L = {L}, L2 = {L2})", flush=True)
         del model
         col = {}
         t0 = time.time()
         orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
-                                      ins["plucker_fea"], ins["plucker_context_lens"], collect=col)
+                                      ins["plucker_fea"], ins["plucker_context_lens"], collect=col,
+                                      control_camera_latents_input=ins.get("control_camera_latents_input"))
         print(f"[{name}] oracle forward {time.time()-t0:.1f}s", flush=True)
         last = cfg.num_layers - 1
         print(f"   oracle vs reference  noise_pred     rel-L2 = {rel(orc, out):.3e}")
@@ -295,7 +310,7 @@ def main_sized(only):
             golden["x_blocks"] = torch.stack([cap["x_blocks"][b] for b in range(cfg.num_layers)]).float()
             golden["tok_blocks"] = torch.stack([cap["tok_blocks"][j] for j in range(cfg.n_irg)]).float()
         golden["meta"] = dict(cfg=ckw, grid=(f, h2, w2), timestep=ts, text_len=tl, uncond=False, seed_weights=0,
-                              seed_inputs=1, torch=torch.__version__, flavour="wan21", sampled_rows=True,
+                              seed_inputs=1, torch=torch.__version__, flavour="wan22" if wan22 else "wan21", sampled_rows=True,
                               reference_forward_s=round(t_ref, 1), cpu_threads=torch.get_num_threads())
         path = os.path.join(ROOT, "tests", "golden", name + ".pt")
         torch.save(golden, path)

@@ -1,10 +1,11 @@
-"""TEST INFRASTRUCTURE ONLY -- harness that imports the *real* reference from /root/reference.
+"""TEST INFRASTRUCTURE ONLY -- harness that imports the *real* reference (located by oracle/ref_locate.py).
 
 Used in the build container (where /root/reference is mounted) to
   (1) pin oracle/fw_oracle.py (the CPU restatement) against the reference's own modules, and
-  (2) generate the golden fixtures under tests/golden/ (see oracle/make_golden.py).
-It cannot travel to the GPU box (no /root/reference there); nothing in the product path
-(fantasy_world_amd/) may import it.
+  (2) generate the golden fixtures under tests/golden/ (see oracle/make_golden.py),
+and on the GPU box -- where the unmodified reference arrives as the git-ignored bundle oracle/_ref/reference_py.tgz staged by
+oracle/stage_ref.sh -- to run the REAL reference modules next to / on top of the HIP path (tests/test_reference_on_gpu.py).
+Nothing in the product path (fantasy_world_amd/) may import it.
 
 What it does:
   * registers permissive stub modules for the non-hot-path imports the container lacks
@@ -25,7 +26,9 @@ import types
 import torch
 import torch.nn as nn
 
-REFERENCE_ROOT = os.environ.get("FW_REFERENCE_ROOT", "/root/reference")
+from oracle import ref_locate
+
+REFERENCE_ROOT = ref_locate.reference_root() or "/root/reference"
 
 _STUB_TOPLEVEL = {
     "diffusers", "modelscope", "torchvision", "imageio", "cv2", "ftfy", "easydict", "decord", "av",
@@ -82,7 +85,8 @@ def install_stubs():
         return
     sys.dont_write_bytecode = True           # reference tree is read-only
     if not os.path.isdir(REFERENCE_ROOT):
-        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT} (expected: the build container)")
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT} (expected: the build container, or the bundle staged "
+                           "by oracle/stage_ref.sh on the GPU box)")
     for name in list(_STUB_TOPLEVEL):
         try:
             importlib.import_module(name)

@@ -13,7 +13,9 @@ import torch
 from conftest import rel_l2
 from oracle.ref_ops import TorchRefOps
 
-pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/FantasyWorld"), reason="reference not mounted")
+from oracle import ref_locate
+
+pytestmark = pytest.mark.skipif(not ref_locate.available(), reason="reference not mounted / staged")
 
 
 def _scaled_mm_definition(a, b, scale_a=None, scale_b=None, bias=None, out_dtype=None, **kw):

@@ -7,8 +7,9 @@ import torch
 
 from conftest import rel_l2
 
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.environ.get("FW_REFERENCE_ROOT", "/root/reference")),
-                                reason="reference tree not mounted")
+from oracle import ref_locate
+
+pytestmark = pytest.mark.skipif(not ref_locate.available(), reason="reference tree not mounted / staged")
 
 
 def test_install_rebinds_joint_forward_on_reference_model(case_l2):

@@ -65,9 +65,9 @@ def test_heads_oracle_matches_live_reference(S, ph, pw):
     reference modules, which decode time frame by frame through the convolution cache -- the oracle's whole-sequence causal
     convolutions and the host logic of fantasy_world_amd.heads (on the torch ops) must both agree.  (A single latent frame is
     not a reference case: CameraHead's time up-sampler fails on an empty sequence, camera_head.py:93.)"""
-    import os
-    if not os.path.isdir("/root/reference/FantasyWorld"):
-        pytest.skip("reference not mounted on this machine")
+    from oracle import ref_locate
+    if not ref_locate.available():
+        pytest.skip("reference not mounted / staged on this machine")
     from conftest import PRED_KEYS
     from fantasy_world_amd import config as fwc, synth, heads as fw_heads
     from oracle import fw_heads_oracle, ref_harness, ref_ops

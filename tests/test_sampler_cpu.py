@@ -29,7 +29,7 @@ def test_scheduler_known_values():
     assert torch.allclose(s.step(v, 49, x), x + v * (0.0 - float(s.sigmas[49])), atol=1e-6)      # last step goes to sigma 0
 
 
-@pytest.mark.skipif(not os.path.isdir("/root/reference/FantasyWorld"), reason="reference not mounted")
+@pytest.mark.skipif(not __import__("oracle.ref_locate", fromlist=["x"]).available(), reason="reference not mounted / staged")
 @pytest.mark.parametrize("steps", [1, 10, 50])
 def test_scheduler_matches_reference(steps):
     from oracle import ref_harness
