@@ -222,44 +222,57 @@ def test_hip_matches_cpu_oracle_on_negative_prompt_and_uncond(case_l2):
         del eng
 
 
-@pytest.mark.parametrize("flavour,grid", [("wan21", (21, 60, 104)), ("wan22", (21, 90, 160))])
-def test_full_size_forward_agrees_across_independent_kernels(flavour, grid):
-    """BASELINE sizes (config 2: 81f x 480 x 832 -> L = 32760; config 4: 81f x 720p -> L = 75600) on a 2-block model: too big
-    for the CPU oracle, so the size-independent check is agreement between INDEPENDENT implementations of the hot kernels --
-    the default path (8-wave ping-pong GEMM, log2-domain single-stream attention) against the four-wave GEMM (128x128 wave
-    tiles, its own DMA order and epilogue) and the first-generation attention kernel (per-tile running max): different tilings,
-    schedules, DMA layouts and softmax algebra, same math.
-    Catches size-dependent addressing bugs (32-bit offsets, tail tiles, ring wrap-around) that small goldens cannot."""
-    from fantasy_world_amd import config as fwc, synth
+FULL_SIZE_GOLDENS = ["wan21_cfg2_l2_f21_60x104", "wan22_cfg4_l2_f21_90x160"]
+
+
+@pytest.mark.parametrize("name", FULL_SIZE_GOLDENS)
+def test_full_size_forward_matches_reference_golden(name, parity):
+    """BASELINE sizes pinned to the REAL reference (round 3): config 2 / 3's token grid (81f x 480 x 832 -> latents
+    [1,16,21,60,104], L = 32760, L2 = 32865) and config 4's (Wan2.2, 81f x 720p -> [1,16,21,90,160], L = 75600, L2 = 75705) on the
+    2-block model.  Golden = the reference's own FantasyWorldFusionModel.joint_forward in fp32 on CPU (oracle/make_golden.py
+    main_sized: 146 s / ~15 min of reference time): noise_pred in full, the two residual streams as 64 sampled rows.
+    First assert: the HIP path against that golden, at the level of the small goldens (2.6-2.8e-3, the bf16 rounding of the
+    activations; physical bound 8e-3).  Second assert (kept from round 2): agreement between INDEPENDENT implementations of the
+    hot kernels -- the default path (8-wave ping-pong GEMM, log2-domain single-stream attention) against the four-wave GEMM and the
+    first-generation attention kernel -- so an addressing error at this size is attributed to a kernel, not to the wiring."""
+    import os
+    from conftest import Case, GOLDEN_DIR
+    if not os.path.exists(os.path.join(GOLDEN_DIR, name + ".pt")):
+        pytest.skip(f"{name}.pt not generated (oracle/make_golden.py {name})")
     from fantasy_world_amd.engine import FusionEngine
     from fantasy_world_amd.hip_ops import HipOps
-    cfg = (fwc.plumbing22 if flavour == "wan22" else fwc.plumbing)(num_layers=2, start_index=1)
+    case = Case(name)
+    g = case.golden
     ops = HipOps("cuda:0")
-    spec = synth.weight_spec(cfg)
-    eng = FusionEngine(cfg, lambda n: synth.make_param(n, spec[n][0], spec[n][1], device="cuda:0"), ops)
-    f, h2, w2 = grid
-    ins = synth.make_inputs(cfg, f, h2, w2, seed=5, device="cuda:0", dtype=torch.bfloat16)
-    kw = dict(clip_feature=ins["clip_feature"], y=ins["y"], plucker_fea=ins["plucker_fea"],
-              plucker_context_lens=ins["plucker_context_lens"])
-    if ins.get("control_camera_latents_input") is not None:
-        kw["control_camera_latents_input"] = ins["control_camera_latents_input"]
-    t = torch.tensor([500.0], device="cuda:0", dtype=torch.bfloat16)
-    a, _ = eng.joint_forward(ins["x"], t, ins["context"], **kw)
+    eng = FusionEngine(case.cfg, case.weights.__getitem__, ops)
+    case.weights.clear()
+    ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
+    kw = forward_kwargs(case, "cuda")
+    col = {}
+    a, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], collect=col, **kw)
     torch.cuda.synchronize()
+    L2 = col["tokens_final"].shape[0]
+    rd, ra = g["rows_dit"].cuda(), g["rows_agg"].cuda()
+    errs = {"noise_pred": rel_l2(a.float(), g["noise_pred"]),
+            "x_after_pcb": rel_l2(col["x_after_pcb"][rd], g["x_after_pcb"]),
+            "x_final": rel_l2(col["x_final"][rd], g["x_final"]),
+            "tokens_final": rel_l2(col["tokens_final"].reshape(L2, -1)[ra], g["tokens_final"])}
+    print(name, {k: f"{v:.2e}" for k, v in errs.items()})
+    del col
+    for k, v in errs.items():
+        parity.check(f"e2e/{name}/{k}", v, E2E_TOL)
     try:
         ops.set_option("gemm_kernel", 5)
         ops.set_option("attn_var", 0)
-        b, _ = eng.joint_forward(ins["x"], t, ins["context"], **kw)
+        b, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
         torch.cuda.synchronize()
     finally:
         ops.set_option("gemm_kernel", 4)
         ops.set_option("attn_var", 192)
-    assert torch.isfinite(a.float()).all() and torch.isfinite(b.float()).all()
-    err = rel_l2(a.float(), b.float())
-    print(flavour, grid, f"default vs baseline kernels rel-L2 = {err:.2e}")
-    # two independent bf16 rounding realisations of the same forward (q is rounded after / before the softmax scale, P sums
-    # differ in order): each is ~2.5e-3 from the fp32 truth on the goldens, so their mutual distance is ~sqrt(2) of that
-    assert err < E2E_TOL, err
+    assert torch.isfinite(b.float()).all()
+    parity.check(f"e2e/{name}/noise_pred_independent_kernels", rel_l2(b.float(), g["noise_pred"]), E2E_TOL)
+    # two independent bf16 rounding realisations of the same forward: each ~2.7e-3 from the fp32 truth, so ~sqrt(2) of that apart
+    parity.check(f"e2e/{name}/default_vs_independent_kernels", rel_l2(a.float(), b.float()), E2E_TOL)
 
 
 PRED_TOL = 1.5e-2
