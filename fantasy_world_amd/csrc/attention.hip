@@ -1215,17 +1215,28 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
 
 }  // namespace
 
+// Split-KV plan for the tail q-block.  It depends on (heads, Lq, Lk) ONLY -- never on the batch: the merged CFG pass runs the
+// same attention with batch 2 (FusionEngine.joint_forward_pair) and must merge a tail row's key runs in the same order as the
+// two separate forwards do, or the pair is no longer bit-identical to them (round-2 advisor finding: target = 256 / (heads *
+// batch) gave 16 runs at batch 1 and 8 at batch 2 for the VGGT global attention at L2 = 32865).  The criterion is the
+// per-sample grid: the tail work-groups of ONE sample would open a new round of the 256 CUs.
+static bool attn_split_plan(int heads, int Lq, int Lk, int* nsplit, int* tps) {
+    const int tail = Lq % QB, nqb_full = Lq / QB;
+    const int nt = (Lk + KVB - 1) / KVB;
+    if (tail == 0 || nqb_full == 0 || nt < 16 || heads > 128) return false;
+    const int64_t w_full = (int64_t)nqb_full * heads, w_all = w_full + heads;
+    if ((w_full + 255) / 256 >= (w_all + 255) / 256) return false;             // the tail work-groups fit the last round anyway
+    const int target = max(2, min(16, 256 / heads));
+    *tps = (nt + target - 1) / target;
+    *nsplit = (nt + *tps - 1) / *tps;
+    return true;
+}
+
 // Bytes of workspace with which fw_attention_bf16 takes the split-KV route for the tail q-block; 0 = it would not use one.
 extern "C" int64_t fw_attention_workspace_bytes(int batch, int heads, int head_dim, int Lq, int Lk) {
     if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0) return 0;
-    const int tail = Lq % QB, nqb_full = Lq / QB;
-    const int64_t w_full = (int64_t)nqb_full * heads * batch, w_all = w_full + (int64_t)heads * batch;
-    const int nt = (Lk + KVB - 1) / KVB;
-    if (tail == 0 || nqb_full == 0 || nt < 16 || heads * batch > 128) return 0;
-    if ((w_full + 255) / 256 >= (w_all + 255) / 256) return 0;                 // the tail work-groups fit the last round anyway
-    const int target = max(2, min(16, 256 / (heads * batch)));
-    const int tps = (nt + target - 1) / target;
-    const int nsplit = (nt + tps - 1) / tps;
+    int nsplit = 0, tps = 0;
+    if (!attn_split_plan(heads, Lq, Lk, &nsplit, &tps)) return 0;
     return (int64_t)batch * heads * nsplit * QB * (head_dim + 2) * (int64_t)sizeof(float);
 }
 
@@ -1258,11 +1269,7 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     if (workspace != nullptr && prescaled) {
         int nsplit = 0, tps = 0;
         const int64_t need = fw_attention_workspace_bytes(batch, heads, head_dim, Lq, Lk);
-        if (need > 0 && workspace_bytes >= need) {
-            const int nt = (Lk + KVB - 1) / KVB;
-            const int target = max(2, min(16, 256 / (heads * batch)));
-            tps = (nt + target - 1) / target;
-            nsplit = (nt + tps - 1) / tps;
+        if (need > 0 && workspace_bytes >= need && attn_split_plan(heads, Lq, Lk, &nsplit, &tps)) {
             const int Lq_main = (Lq / QB) * QB;
             int rc = fw_attention_bf16(Q, ldq, bsq, K, ldk, bsk, Vt, Lk_pad, O, ldo, bso, batch, heads, head_dim, Lq_main, Lk,
                                        scale, flags, nullptr, 0, stream);

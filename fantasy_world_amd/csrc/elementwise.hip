@@ -441,6 +441,11 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
         float* mine = strow[threadIdx.x >> 6];
         if (lane * 2 < hd) *(u32x2_t*)(mine + lane * 2) = *(const u32x2_t*)(grow + lane * 2);
         trow = mine;
+        // the strip is written and read by the lanes of ONE wave: a wavefront-scope release/acquire pair + wave barrier keeps the
+        // compiler from moving the cross-lane reads above the store (lockstep alone is not a language guarantee)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -475,6 +480,10 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
             *(u32x4_t*)(xr + ch * 8) = o4;
         }
+    }
+    if (ROPE != FW_ROPE_NONE) {     // this row's strip reads are done before the next row's strip store
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
     }       // row loop
 }

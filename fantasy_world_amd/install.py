@@ -59,20 +59,97 @@ def heads_config_from_model(vggt):
         point_out=pts.scratch.output_conv2[2].out_channels)
 
 
-def _weight_signature(params):
-    """(storage address, in-place version) of a spread of parameters: cheap evidence that the live module tree still holds the
-    tensors that were packed (load_state_dict / LoRA merge / .to() after install() change one or the other)."""
-    names = sorted(params)
-    pick = names[:: max(1, len(names) // 24)]
-    return tuple((n, params[n].data_ptr(), params[n]._version) for n in pick)
+class _WeightWatch:
+    """Cheap evidence that the live module tree still holds the tensors that were packed: a spread of ~24 parameters is
+    remembered BY MODULE AND NAME at install time and re-read per call (no walk over the module tree): load_state_dict, a LoRA
+    merge done with in-place tensor ops, `.to()` / `.half()` or re-assigned Parameters change the storage address or the in-place
+    version counter of at least the sampled tensors.
+    NOT detected: edits that go through `.data` (`p.data += delta`, `p.data.add_(...)`) -- autograd's version counter does not
+    see them and the address stays; call `install(model)` again after such a merge, or `verify()` (one device sync: compares
+    content checksums of the sampled tensors with the ones taken at install time)."""
+
+    def __init__(self, model, every=24):
+        named = sorted(model.named_parameters(), key=lambda kv: kv[0])
+        pick = named[:: max(1, len(named) // every)]
+        mods = dict(model.named_modules())
+        self.slots = []
+        for name, _ in pick:
+            owner, _, leaf = name.rpartition(".")
+            self.slots.append((name, mods[owner], leaf))
+        self.signature = self._read()
+        self.checksums = self._sums()
+
+    def _read(self):
+        out = []
+        for name, mod, leaf in self.slots:
+            p = mod._parameters.get(leaf)
+            out.append((name, None, None) if p is None else (name, p.data_ptr(), p._version))
+        return tuple(out)
+
+    def _sums(self):
+        vals = [mod._parameters[leaf].detach().reshape(-1)[:4096].double().sum() for _, mod, leaf in self.slots
+                if mod._parameters.get(leaf) is not None]
+        return torch.stack(vals).cpu() if vals else torch.zeros(0)
+
+    def unchanged(self):
+        return self._read() == self.signature
+
+    def verify(self):
+        """Content check of the sampled tensors (syncs the device once): also catches `.data` edits."""
+        return self.unchanged() and torch.equal(self._sums(), self.checksums)
 
 
-def install(model, ops=None, device=None, cache_step_invariants=True, precision="bf16"):
+class CfgPairing:
+    """CFG parallelism UNDER the reference's unchanged sampling loop (model_wan21.py:289-322; inference_wan22.py:229-277).
+
+    The loop calls joint_forward twice per step -- positive prompt, then negative prompt -- with the SAME latents and timestep
+    objects and, step after step, the SAME two context tensors.  With two CFG rank groups (parallel.Topology.cfg_groups == 2)
+    the rebound joint_forward learns that pair during the first step (both groups compute both forwards, like one group would),
+    and from the second step on runs the two forwards of a step CONCURRENTLY: at the positive call group 0 computes the positive
+    and group 1 the negative forward, the two noise predictions are exchanged with one all-gather (4 MB), the positive one is
+    returned and the negative one is kept for the call that follows; that call is recognised by identity (same latents object,
+    same timestep object, the learned negative context) and answered from the stash.  Anything else -- another prompt,
+    uncond=True, return_prediction=True (the last step needs the positive pass's geometry on every rank) -- takes the plain
+    path and re-learns.  Every rank runs the same script on the same inputs, so every rank takes the same branch and returns
+    the same tensors as a single-GPU run."""
+
+    def __init__(self, topo):
+        self.topo = topo
+        self.pair = None          # (first context, second context) of a step, learned
+        self.last = None          # (x, timestep, context) of the previous plain call
+        self.stash = None         # (x, timestep, second-context result) waiting for the second call
+
+    def run(self, forward, x, timestep, context, uncond, return_prediction):
+        """forward(context, want_prediction) -> (out, prediction) on this rank's sequence-shard group."""
+        plain = uncond or return_prediction
+        st = self.stash
+        if st is not None and not plain and st[0] is x and st[1] is timestep and self.pair is not None and context is self.pair[1]:
+            self.stash = None
+            return st[2], None
+        self.stash = None
+        if not plain and self.pair is not None and context is self.pair[0]:
+            out, _ = forward(self.pair[self.topo.cfg_rank], False)
+            first, second = self.topo.gather_cfg(out)
+            self.stash = (x, timestep, second)
+            return first, None
+        if self.last is not None and self.last[0] is x and self.last[1] is timestep and self.last[2] is not context:
+            self.pair = (self.last[2], context)
+        self.last = (x, timestep, context)
+        return forward(context, return_prediction)
+
+
+def install(model, ops=None, device=None, cache_step_invariants=True, precision="bf16", topo=None, shard=None):
     """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
     tests may inject another op set to exercise this boundary on CPU.  `cache_step_invariants`: keep the context embeddings,
     the per-block cross-attention K/V and the camera adapter's Pluecker term across the calls of a generation (the caller
     passes the same tensors 100 times; results are bit-identical).  `precision`: "bf16", or "fp8" = the
     DiT blocks' linears through the reference's fp8 linear.
+
+    Several GPUs (one process per GPU, every process running the SAME reference script on the same inputs): pass
+    `topo=fantasy_world_amd.parallel.init_topology()` (or a bare `shard=SequenceShard(...)`).  The forward is then
+    sequence-sharded over the ranks of this process's group (head all-to-all, parallel.py) and, with two CFG groups, the two
+    forwards of a sampling step run concurrently under the unchanged reference loop (CfgPairing).  Every rank returns the full
+    noise prediction (and, on the last step, the full prediction dict), identical across ranks.
 
     The weights are SNAPSHOT at install time into packed copies (36 GB for the 14B model, next to the reference's own): call
     install() after checkpoint loading / LoRA merging / .to(dtype).  A later change of the live parameters is detected at the
@@ -85,22 +162,32 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
         from .hip_ops import HipOps
         ops = HipOps(device or "cuda")
     cfg = config_from_model(model)
+    if topo is not None:
+        assert shard is None or shard is topo.shard, "pass either topo or shard"
+        shard = topo.shard
+    pairing = CfgPairing(topo) if topo is not None and topo.cfg_groups == 2 else None
     params = dict(model.named_parameters())
     engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
-                          cache_step_invariants=cache_step_invariants, precision=precision)
-    signature = _weight_signature(params)
+                          cache_step_invariants=cache_step_invariants, precision=precision, shard=shard)
+    watch = _WeightWatch(model)
+    engine.weight_watch = watch
+    del params
 
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
                       camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,
                       return_prediction=False, control_camera_latents_input=None, **kwargs):
-        if _weight_signature(dict(self.named_parameters())) != signature:
+        if not watch.unchanged():
             raise RuntimeError("the model's parameters changed after fantasy_world_amd.install() (load_state_dict, LoRA merge, "
                                ".to()): the engine runs on a packed snapshot -- call install(model) again")
-        out, outputs = engine.joint_forward(x, timestep, context, clip_feature=clip_feature, y=y,
-                                            plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
-                                            uncond=uncond, return_prediction=return_prediction,
-                                            camera_token=camera_token,
-                                            control_camera_latents_input=control_camera_latents_input)
+        def forward(ctx, want_prediction):
+            return engine.joint_forward(x, timestep, ctx, clip_feature=clip_feature, y=y,
+                                        plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
+                                        uncond=uncond, return_prediction=want_prediction, camera_token=camera_token,
+                                        control_camera_latents_input=control_camera_latents_input)
+        if pairing is not None:
+            out, outputs = pairing.run(forward, x, timestep, context, uncond, return_prediction)
+        else:
+            out, outputs = forward(context, return_prediction)
         if not return_prediction:
             return out, None
         if engine.heads_cfg is not None:
@@ -123,6 +210,7 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     model._fw_reference_joint_forward = model.joint_forward
     model.joint_forward = types.MethodType(joint_forward22 if cfg.control_adapter else joint_forward, model)
     model._fw_engine = engine
+    engine.cfg_pairing = pairing
 
     # Wan2.1: the producer of plucker_fea (CameraConditionModel.get_pose_fea, camera_control.py:233-234; called once per
     # generation from generate_video, model_wan21.py:271) moves onto the same op set; packed on first use

@@ -137,7 +137,14 @@ def measure(cfg, F, h, w, budget_s=60.0, reference_root=None):
     """-> dict for bench.py's `cpu_baseline` (value in denoise-steps/s) plus the raw timings (profiles/rNN/cpu_baseline.json)."""
     from oracle import ref_locate
     root = reference_root or ref_locate.reference_root()
-    blocks = _ReferenceBlocks(cfg) if root and os.path.isdir(os.path.join(root, "FantasyWorld")) else _PortBlocks(cfg)
+    blocks, ref_error = None, None
+    if root and os.path.isdir(os.path.join(root, "FantasyWorld")):
+        try:
+            blocks = _ReferenceBlocks(cfg)
+        except Exception as e:                     # a host that cannot import the reference must not cost the bench its line
+            ref_error = f"{type(e).__name__}: {e}"[:300]
+    if blocks is None:
+        blocks = _PortBlocks(cfg)
     Lc = 512 + (cfg.clip_tokens if cfg.has_image_input else 0)
     ncpu = os.cpu_count() or 1
     hw = h * w
@@ -189,7 +196,7 @@ def measure(cfg, F, h, w, budget_s=60.0, reference_root=None):
                    f"{ {k: round(v / 1e12, 2) for k, v in sweep.items()} } TFLOP/s){scaled}; step = 2 x [{n_pcb} t_PCB + "
                    f"{n_irg} (t_frame + t_DiT + t_global + t_bicross)] = {t_step:.0f} s (embeddings, head"
                    + ("" if blocks.adapter else ", camera adapter") + " not counted)"),
-        "raw": {"seconds_timed": t, "seconds_full_size": t_full, "flops_timed": part, "flops_full_size": full,
+        "raw": {"reference_import_error": ref_error, "seconds_timed": t, "seconds_full_size": t_full, "flops_timed": part, "flops_full_size": full,
                 "thread_sweep_flops_per_s": {str(k): v for k, v in sweep.items()}, "frames_timed": f_s, "frames": F,
                 "grid_hw": [h, w], "step_seconds": t_step},
     }

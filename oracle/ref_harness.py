@@ -61,13 +61,42 @@ class _StubModule(types.ModuleType):
         return type(name, (_Anything,), {})
 
 
+# never stubbed: their ABSENCE selects the reference's SDPA branch (wan_video_dit.py:28-66, block.py:26, attention.py:18)
+_NEVER_STUB = {"flash_attn", "flash_attn_interface", "sageattention", "xformers"}
+
+
+def _imported_from_reference():
+    """True when the import statement being resolved sits in a file of the reference tree."""
+    f = sys._getframe(2)
+    while f is not None:
+        name = f.f_code.co_filename
+        if "importlib" not in name and not name.startswith("<frozen"):
+            return name.startswith(REFERENCE_ROOT)
+        f = f.f_back
+    return False
+
+
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Last finder on sys.meta_path: only consulted for modules nothing else can import.  Stubs the known non-hot-path
+    dependencies, and ANY other missing top-level package that a file of the reference tree asks for (the GPU box lacks some
+    that the build container has, e.g. huggingface_hub) -- never one of _NEVER_STUB."""
+
     def find_spec(self, fullname, path, target=None):
-        if fullname.split(".")[0] in _STUB_TOPLEVEL:
+        top = fullname.split(".")[0]
+        if top in _NEVER_STUB:
+            return None
+        if top in _STUB_TOPLEVEL or top in _stubbed_dynamic or _imported_from_reference():
+            _stubbed_dynamic.add(top)
             return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
         return None
 
     def create_module(self, spec):
+        if spec.name == "tqdm":                # generate_video iterates tqdm(range(n)) (model_wan21.py:289-290): must stay iterable
+            m = types.ModuleType("tqdm")
+            m.tqdm = lambda it=None, *a, **k: it
+            m.trange = lambda *a, **k: range(*a)
+            m.__path__ = []
+            return m
         m = _StubModule(spec.name)
         m.__path__ = []
         return m
@@ -75,6 +104,8 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def exec_module(self, module):
         pass
 
+
+_stubbed_dynamic = set()
 
 _installed = False
 

@@ -17,6 +17,16 @@ def pytest_configure(config):
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
 
 
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a machine without a GPU: the gpu-marked tests skip instead of erroring in their fixtures."""
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (torch.cuda.is_available() is False)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def rel_l2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

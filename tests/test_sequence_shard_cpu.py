@@ -243,3 +243,108 @@ def test_eight_rank_topology_collectives(tmp_path):
     mp.spawn(_topology_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
     d = torch.load(os.path.join(str(tmp_path), "d_0.pt"))
     assert "CFG-parallel x2" in d and "x4" in d
+
+
+def _pairing_worker(rank, world, port, grid, outdir, wpath):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from fantasy_world_amd import synth
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.install import CfgPairing
+    from fantasy_world_amd.parallel import make_topology
+    from fantasy_world_amd.sampler import FlowMatchScheduler
+    from oracle.ref_ops import TorchRefOps
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    topo = make_topology(rank, world)
+    cfg = _cfg()
+    W = _load_weights(wpath)
+    ins = synth.make_inputs(cfg, *grid, seed=3)
+    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(), shard=topo.shard)
+    cond = dict(clip_feature=ins["clip_feature"], y=ins["y"], plucker_fea=ins["plucker_fea"],
+                plucker_context_lens=ins["plucker_context_lens"])
+    pairing = CfgPairing(topo)
+    sched = FlowMatchScheduler()
+    sched.set_timesteps(4)
+    latents, calls = ins["x"], []
+    # the reference's loop (model_wan21.py:289-322): positive call, negative call with the SAME latents / timestep objects
+    for step in range(3):
+        t = sched.timesteps[step].reshape(1)
+
+        def fwd(ctx, want, latents=latents, t=t):
+            calls.append(step)
+            return eng.joint_forward(latents, t, ctx, return_prediction=want, **cond)
+        pos, _ = pairing.run(fwd, latents, t, ins["context"], False, False)
+        neg, _ = pairing.run(fwd, latents, t, ins["context_neg"], False, False)
+        latents = sched.step(neg + 5.0 * (pos - neg), step, latents)
+    torch.save((latents, calls), os.path.join(outdir, f"pair_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg_pairing_under_the_reference_loop(world, tmp_path, shared_weights):
+    """install(model, topo=...) keeps the reference's sampling loop unchanged: two sequential joint_forward calls per step.
+    CfgPairing learns the (positive, negative) context pair during the first step and runs the two forwards of every later step
+    concurrently on the two CFG groups (world 2: 2 x 1 rank; world 4: 2 x 2-way sequence shard), answering the second call from
+    the stash.  Three steps: every rank computes 2 + 1 + 1 forwards and ends with the single-process latents."""
+    from fantasy_world_amd import synth
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step
+    from oracle.ref_ops import TorchRefOps
+    grid = (2, 8, 8)
+    cfg = _cfg()
+    W, wpath = shared_weights
+    ins = synth.make_inputs(cfg, *grid, seed=3)
+    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps())
+    cond = dict(clip_feature=ins["clip_feature"], y=ins["y"], plucker_fea=ins["plucker_fea"],
+                plucker_context_lens=ins["plucker_context_lens"])
+    sched = FlowMatchScheduler()
+    sched.set_timesteps(4)
+    want = ins["x"]
+    for step in range(3):
+        want, _ = denoise_step(eng, sched, step, want, ins["context"], ins["context_neg"], cond)
+    del eng
+    mp.spawn(_pairing_worker, args=(world, _free_port(), grid, str(tmp_path), wpath), nprocs=world, join=True)
+    for r in range(world):
+        got, calls = torch.load(os.path.join(str(tmp_path), f"pair_{r}.pt"))
+        assert calls == [0, 0, 1, 2], (r, calls)
+        err = ((got.double() - want.double()).norm() / want.double().norm()).item()
+        assert err < 1e-5, (r, err)
+
+
+def test_cfg_pairing_falls_back_when_the_pattern_breaks():
+    """Single process, fake topology: a new prompt, uncond=True or return_prediction=True take the plain path; a stale stash is
+    never served for other latents."""
+    from fantasy_world_amd.install import CfgPairing
+
+    class Topo:
+        cfg_rank, cfg_groups = 0, 2
+
+        def gather_cfg(self, out):
+            return out, out + 100.0
+    log = []
+    pairing = CfgPairing(Topo())
+    a, b, c = torch.zeros(1), torch.ones(1), torch.full((1,), 2.0)
+
+    def mk(x):
+        def fwd(ctx, want):
+            log.append((float(x), float(ctx), want))
+            return x + ctx, ({"p": 1} if want else None)
+        return fwd
+    x0, t0 = torch.tensor([10.0]), torch.tensor([0.5])
+    assert pairing.run(mk(x0), x0, t0, a, False, False)[0].item() == 10.0 and pairing.pair is None
+    assert pairing.run(mk(x0), x0, t0, b, False, False)[0].item() == 11.0 and pairing.pair[0] is a and pairing.pair[1] is b
+    x1, t1 = torch.tensor([20.0]), torch.tensor([0.4])
+    n = len(log)
+    assert pairing.run(mk(x1), x1, t1, a, False, False)[0].item() == 20.0          # paired: this rank (group 0) computes `a` only
+    assert pairing.run(mk(x1), x1, t1, b, False, False)[0].item() == 120.0         # from the stash (fake gather: +100)
+    assert len(log) == n + 1
+    x2 = torch.tensor([30.0])
+    pairing.run(mk(x2), x2, t1, a, False, False)
+    assert pairing.run(mk(x2), torch.tensor([30.0]), t1, b, False, False)[0].item() == 31.0   # other latents object: stash refused
+    out, pred = pairing.run(mk(x2), x2, t1, a, False, True)                        # last step: plain, prediction returned
+    assert pred == {"p": 1} and pairing.stash is None
+    assert pairing.run(mk(x2), x2, t1, c, False, False)[0].item() == 32.0          # unknown prompt: plain, pair re-learned
+    assert pairing.pair[0] is a and pairing.pair[1] is c
