@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--cache-invariants", action="store_true")
     ap.add_argument("--merge-cfg", action="store_true", help="N = 1: the two CFG forwards of a step as ONE pass over 2L rows")
     ap.add_argument("--experts", type=int, default=None, help="wan22: resident experts (default 2; 1 = high-noise only)")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="N = 1: after the timed (eager) region, capture one whole step in a HIP graph and time the same number of "
+                         "replays -- reported in a `hip_graph` block, never as `value` (SURVEY.md 8(f) item 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="bound on the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true",
@@ -221,8 +224,9 @@ def main():
         "attn_hd128_cross": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] < 1024,
         "attn_hd96_bicross_dit_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] >= L2,
         "attn_hd96_bicross_vggt_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] < L2,
-        "attn_hd64_global": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["batch"] == 1,
-        "attn_hd64_frame": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["batch"] > 1,
+        # frame vs global by the key count (P keys per frame vs all L2 tokens): the merged CFG pass runs both with batch > 1
+        "attn_hd64_global": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["Lk"] > P,
+        "attn_hd64_frame": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["Lk"] <= P,
         "gemm_qkv": lambda i: i["kind"] == "linear" and i["N"] == 3 * cfg.dim and i["K"] == cfg.dim,
         "gemm_ffn0": lambda i: i["kind"] == "linear" and i["N"] == cfg.ffn_dim,
         "gemm_ffn2_gate_residual": lambda i: i["kind"] == "linear" and i["K"] == cfg.ffn_dim,
@@ -252,17 +256,20 @@ def main():
     # (sharded: L rows x 40/n heads per rank after the head exchange = the same FLOPs as L/n rows x 40 heads; a block's heads
     #  go through the kernel in groups under the shard (FusionEngine._head_groups): average per launch)
     n_groups = len(eng._head_groups(cfg.num_heads // sp)) if shard is not None and shard.heads_divisible(cfg.num_heads) else 1
-    attn_flops = 4.0 * L * L * cfg.dim / sp / n_groups
+    # --merge-cfg: one launch carries both samples (batch 2 / 2L rows): twice the FLOPs per launch
+    nb = 2 if (args.merge_cfg and world == 1) else 1
+    attn_flops = nb * 4.0 * L * L * cfg.dim / sp / n_groups
     attn_ms, attn_n = timed["attn_hd128_self"]
     achieved = attn_flops / (attn_ms * 1e-3) if attn_n else 0.0
     Ll, L2l = L / sp, L2 / sp
     kflops = {"attn_hd128_cross": None,      # two launches of different Lk (512 / 257) share the tag: reported as time only
-              "attn_hd96_bicross_dit_queries": 4.0 * Ll * L2 * cfg.bicross_dim,
-              "attn_hd96_bicross_vggt_queries": 4.0 * L2l * L * cfg.bicross_dim,
-              "attn_hd64_global": 4.0 * L2 * L2 * cfg.vggt_dim / sp,
-              "attn_hd64_frame": 4.0 * (F / sp) * P * P * cfg.vggt_dim,
-              "gemm_qkv": 2.0 * Ll * 3 * cfg.dim * cfg.dim, "gemm_ffn0": 2.0 * Ll * cfg.dim * cfg.ffn_dim,
-              "gemm_ffn2_gate_residual": 2.0 * Ll * cfg.dim * cfg.ffn_dim, "gemm_o_gate_residual": 2.0 * Ll * cfg.dim * cfg.dim}
+              "attn_hd96_bicross_dit_queries": nb * 4.0 * Ll * L2 * cfg.bicross_dim,
+              "attn_hd96_bicross_vggt_queries": nb * 4.0 * L2l * L * cfg.bicross_dim,
+              "attn_hd64_global": nb * 4.0 * L2 * L2 * cfg.vggt_dim / sp,
+              "attn_hd64_frame": nb * 4.0 * (F / sp) * P * P * cfg.vggt_dim,
+              "gemm_qkv": nb * 2.0 * Ll * 3 * cfg.dim * cfg.dim, "gemm_ffn0": nb * 2.0 * Ll * cfg.dim * cfg.ffn_dim,
+              "gemm_ffn2_gate_residual": nb * 2.0 * Ll * cfg.dim * cfg.ffn_dim,
+              "gemm_o_gate_residual": nb * 2.0 * Ll * cfg.dim * cfg.dim}
     kernels = {}
     for name, (ms, n) in timed.items():
         if name == "attn_hd128_self" or not n:
@@ -314,11 +321,34 @@ def main():
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
                      "flops_per_launch": attn_flops, "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*/pmc_traffic.json)",
-                     "algorithmic_bytes_per_launch": 4.0 * L * cfg.dim * 2 / sp / n_groups},
+                     "algorithmic_bytes_per_launch": nb * 4.0 * L * cfg.dim * 2 / sp / n_groups},
         "kernels": kernels,
     }
     if args.precision == "fp8":
         out["mfma_frac_whole_step_vs_fp8_peak"] = step_flops * value / (world * peak)
+    if args.hip_graph and world == 1 and n_experts == 1:
+        from fantasy_world_amd.sampler import GraphedDenoiseStep
+        t0 = time.time()
+        gstep = GraphedDenoiseStep(eng, sched, latents, ins["context"], ins["context_neg"], cond, merge_cfg=args.merge_cfg)
+        torch.cuda.synchronize()
+        t_cap = time.time() - t0
+        lat_g = latents
+        gid = step_id
+        lat_g = gstep.step(gid, lat_g)          # one untimed replay
+        gid += 1
+        barrier()
+        t0 = time.time()
+        for _ in range(args.steps):
+            lat_g = gstep.step(gid, lat_g)
+            gid += 1
+        barrier()
+        dtg = time.time() - t0
+        assert torch.isfinite(lat_g.float()).all()
+        out["hip_graph"] = {"ms_per_step": 1e3 * dtg / args.steps, "steps": args.steps, "eager_ms_per_step": 1e3 * dt / args.steps,
+                            "gain": dt / dtg - 1.0, "capture_s": round(t_cap, 2),
+                            "note": "one whole denoise step (2 forwards + fw_cfg_euler_step) captured once, replayed per step; "
+                                    "timestep / (cfg_scale, dsigma) / latents fed through device buffers; `value` stays the eager number"}
+        del gstep
     if comm is not None:
         comm["note"] = ("per GPU (this is rank 0); exposed = time the compute stream was blocked inside Pending.wait(); "
                         "issue_to_done = issue -> completion windows summed (upper bound on the exchanges' own duration)")

@@ -215,7 +215,8 @@ constexpr int QK_MAXW = 6144;
 
 __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, int64_t ldx, int heads, int hd,
                                                       int norm_mode, const float* __restrict__ nw, const float* __restrict__ nb,
-                                                      float eps, int rope_mode, const float* __restrict__ tab, int tab_rows, float oscale) {
+                                                      float eps, int rope_mode, const float* __restrict__ tab, int tab_rows, float oscale,
+                                                      const float* __restrict__ ext_ss, int norm_width) {
     __shared__ float rowbuf[QK_MAXW];
     __shared__ float red[4];
     const int row = blockIdx.x;
@@ -239,8 +240,10 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
         }
     }
     if (norm_mode == FW_NORM_RMS_FULL) {
-        const float tot = block_sum_256(ss, red);
-        const float r = rsqrtf(tot / (float)width + eps);
+        // ext_ss: the row's sum of squares over the FULL width (norm_width) when this call only holds a column slice of it
+        // (head-sharded tensor parallelism: the partial sums are all-reduced between fw_row_sumsq and this call)
+        const float tot = ext_ss ? ext_ss[row] : block_sum_256(ss, red);
+        const float r = rsqrtf(tot / (float)(ext_ss ? norm_width : width) + eps);
 #pragma unroll
         for (int i = 0; i < QK_MAXC; ++i) {
             const int ch = threadIdx.x + i * 256;
@@ -356,7 +359,8 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
 template <int CPL, int NORM, int ROPE>
 __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int heads, int hd,
                                                            const float* __restrict__ nw, const float* __restrict__ nb, float eps,
-                                                           const float* __restrict__ tab, int tab_rows, float oscale) {
+                                                           const float* __restrict__ tab, int tab_rows, float oscale,
+                                                           const float* __restrict__ ext_ss, int norm_width) {
     const int lane = threadIdx.x & 63;
     const int width = heads * hd;
     const int nch = width >> 3;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
         for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
     }
     if (NORM == FW_NORM_RMS_FULL) {
-        const float r = rsqrtf(wave_sum(ss) / (float)width + eps);
+        const float r = ext_ss ? rsqrtf(ext_ss[row] / (float)norm_width + eps) : rsqrtf(wave_sum(ss) / (float)width + eps);
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int ch = lane + 64 * i;
@@ -490,10 +494,11 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
 
 template <int CPL>
 static bool launch_qk_wave(hipStream_t st, uint16_t* x, int64_t ldx, int rows, int heads, int hd, int norm, const float* nw,
-                           const float* nb, float eps, int rope, const float* tab, int tab_rows, float oscale) {
+                           const float* nb, float eps, int rope, const float* tab, int tab_rows, float oscale,
+                           const float* ext_ss, int norm_width) {
     // RMS_FULL stages 20 KiB of weights per work-group and walks the rows: 4 work-groups per CU; the other modes: one row per wave
     const dim3 grid(norm == FW_NORM_RMS_FULL ? min((rows + 3) / 4, 256 * 4) : (rows + 3) / 4), block(256);
-#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale); return true; }
+#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width); return true; }
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_INTERLEAVED)
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_NONE)
     FW_QK_CASE(FW_NORM_NONE, FW_ROPE_INTERLEAVED)
@@ -670,14 +675,15 @@ extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_
     return (int)hipGetLastError();
 }
 
-extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
-                          const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
-                          void* stream) {
+static int qk_prep_impl(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
+                        const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                        const float* ext_ss, int norm_width, void* stream) {
     if (rows <= 0) return 0;
     const int width = heads * head_dim;
     if (width > QK_MAXW || (head_dim % 8) || (ldx % 8) || (((uintptr_t)x) & 15)) { fw_set_error("fw_qk_prep: width <= 6144, head_dim % 8 == 0, 16-B alignment required"); return FW_E_BADARG; }
     if (norm_mode == FW_NORM_LN_HEAD && (head_dim != 64 || !norm_w || !norm_b)) { fw_set_error("fw_qk_prep: LN_HEAD needs head_dim 64 and weight+bias"); return FW_E_BADARG; }
     if (norm_mode == FW_NORM_RMS_FULL && !norm_w) { fw_set_error("fw_qk_prep: RMS_FULL needs a weight"); return FW_E_BADARG; }
+    if (ext_ss && (norm_mode != FW_NORM_RMS_FULL || norm_width < width)) { fw_set_error("fw_qk_prep_tp: external statistics need RMS_FULL and norm_width >= the slice width"); return FW_E_BADARG; }
     if (rope_mode != FW_ROPE_NONE && (!rope_tab || tab_rows <= 0)) { fw_set_error("fw_qk_prep: rope table missing"); return FW_E_BADARG; }
     if (rope_mode == FW_ROPE_HALF2D && (head_dim % 32)) { fw_set_error("fw_qk_prep: HALF2D needs head_dim % 32 == 0"); return FW_E_BADARG; }
     {   // wave-per-row fast path (table rows and norm vectors 16-B aligned; rotate-half form only for head_dim 64)
@@ -688,14 +694,136 @@ extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int hea
             const int cpl = (width / 8 + 63) / 64;
             hipStream_t st = (hipStream_t)stream;
             bool ok = false;
-            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
-            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
-            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
+            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
+            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
+            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
             if (ok) return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL(qk_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, heads, head_dim, norm_mode,
-                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale);
+                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
+                          const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                          void* stream) {
+    return qk_prep_impl(x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale,
+                        nullptr, 0, stream);
+}
+
+extern "C" int fw_qk_prep_tp(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, const float* norm_w, float eps,
+                             int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                             const float* row_sumsq, int norm_width, void* stream) {
+    if (!row_sumsq) { fw_set_error("fw_qk_prep_tp: row_sumsq missing"); return FW_E_BADARG; }
+    return qk_prep_impl(x, ldx, rows, heads, head_dim, FW_NORM_RMS_FULL, norm_w, nullptr, eps, rope_mode, rope_tab, tab_rows,
+                        out_scale, row_sumsq, norm_width, stream);
+}
+
+// ---- head-sharded tensor parallelism helpers (fantasy_world_amd/tensor_parallel.py) ---------------------------------------------
+// per-row sum of squares of a bf16 slice, fp32: one wave per row
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const uint16_t* __restrict__ x, int64_t ldx, int rows, int width,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t* xr = x + (int64_t)row * ldx;
+    float ss = 0.f;
+    for (int c = lane * 8; c < width; c += 512) {
+        const u32x4_t raw = *(const u32x4_t*)(xr + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = __uint_as_float(raw[j] << 16), b = __uint_as_float(raw[j] & 0xffff0000u);
+            ss += a * a + b * b;
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) out[row] = ss;
+}
+
+extern "C" int fw_row_sumsq(const uint16_t* x, int64_t ldx, int rows, int width, float* out, void* stream) {
+    if (rows <= 0) return 0;
+    if ((width % 8) || (ldx % 8) || (((uintptr_t)x) & 15)) { fw_set_error("fw_row_sumsq: width % 8 == 0 and 16-B alignment required"); return FW_E_BADARG; }
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, width, out);
+    return (int)hipGetLastError();
+}
+
+// x[r][c] += (y[r][c] + bias[c]) * g1[c] + g0[c]: the epilogue of a row-parallel GEMM AFTER its partial sums were all-reduced
+template <bool YF32>
+__global__ __launch_bounds__(256) void residual_add_kernel(float* __restrict__ x, int64_t ldx, const void* __restrict__ yv, int64_t ldy,
+                                                           int rows, int C, const float* __restrict__ bias,
+                                                           const float* __restrict__ g1, const float* __restrict__ g0) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (i >= (int64_t)rows * c4) return;
+    const int r = (int)(i / c4), c = (int)(i % c4) * 4;
+    float v[4];
+    if (YF32) {
+        const f32x4_t y = *(const f32x4_t*)((const float*)yv + (int64_t)r * ldy + c);
+        v[0] = y[0]; v[1] = y[1]; v[2] = y[2]; v[3] = y[3];
+    } else {
+        const u32x2_t y = *(const u32x2_t*)((const uint16_t*)yv + (int64_t)r * ldy + c);
+        v[0] = __uint_as_float(y[0] << 16); v[1] = __uint_as_float(y[0] & 0xffff0000u);
+        v[2] = __uint_as_float(y[1] << 16); v[3] = __uint_as_float(y[1] & 0xffff0000u);
+    }
+    f32x4_t xo = *(f32x4_t*)(x + (int64_t)r * ldx + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = v[j] + (bias ? bias[c + j] : 0.f);
+        t = fw_affine(t, g1 ? g1[c + j] : 1.f, g0 ? g0[c + j] : 0.f);
+        xo[j] += t;
+    }
+    *(f32x4_t*)(x + (int64_t)r * ldx + c) = xo;
+}
+
+extern "C" int fw_residual_add(float* x, int64_t ldx, const void* y, int64_t ldy, int y_dtype, int rows, int C,
+                               const float* bias, const float* g1, const float* g0, void* stream) {
+    if (rows <= 0) return 0;
+    if ((C % 4) || (ldx % 4) || (ldy % 4) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7) || (y_dtype != FW_DT_BF16 && y_dtype != FW_DT_F32)) {
+        fw_set_error("fw_residual_add: C % 4 == 0, aligned rows, bf16 / f32 y required"); return FW_E_BADARG; }
+    const int64_t n = (int64_t)rows * (C / 4);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (y_dtype == FW_DT_F32) hipLaunchKernelGGL(residual_add_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C, bias, g1, g0);
+    else hipLaunchKernelGGL(residual_add_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, C, bias, g1, g0);
+    return (int)hipGetLastError();
+}
+
+// ---- sampler step on the device -------------------------------------------------------------------------
+// out = latents + (neg + s * (pos - neg)) * dsigma: the CFG combine (model_wan21.py:318-319) and the flow-match Euler update
+// (flow_match.py:43-53) in ONE launch, with the roundings of the reference's five tensor ops: every intermediate is rounded to the
+// tensors' dtype (bf16 tensors) / computed without contraction (fp32 tensors), so the result is BIT-identical to the PyTorch
+// sequence.  params (optional, device): [s, dsigma] read by the kernel instead of the host values -- a captured HIP graph then
+// replays with per-step values.
+template <bool BF16>
+__global__ __launch_bounds__(256) void cfg_euler_step_kernel(const void* __restrict__ posv, const void* __restrict__ negv,
+                                                             const void* __restrict__ latv, void* __restrict__ outv, int64_t n,
+                                                             float s, float ds, const float* __restrict__ params) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (params) { s = params[0]; ds = params[1]; }
+    float p, q, x;
+    if (BF16) {
+        p = bf16_bits_to_f32(((const uint16_t*)posv)[i]); q = bf16_bits_to_f32(((const uint16_t*)negv)[i]);
+        x = bf16_bits_to_f32(((const uint16_t*)latv)[i]);
+        const float d = bf16_bits_to_f32(f32_to_bf16_bits(__fsub_rn(p, q)));
+        const float e = bf16_bits_to_f32(f32_to_bf16_bits(__fmul_rn(d, s)));
+        const float np = bf16_bits_to_f32(f32_to_bf16_bits(__fadd_rn(q, e)));
+        const float m = bf16_bits_to_f32(f32_to_bf16_bits(__fmul_rn(np, ds)));
+        ((uint16_t*)outv)[i] = f32_to_bf16_bits(__fadd_rn(x, m));
+    } else {
+        p = ((const float*)posv)[i]; q = ((const float*)negv)[i]; x = ((const float*)latv)[i];
+        const float np = __fadd_rn(q, __fmul_rn(__fsub_rn(p, q), s));
+        ((float*)outv)[i] = __fadd_rn(x, __fmul_rn(np, ds));
+    }
+}
+
+extern "C" int fw_cfg_euler_step(const void* pos, const void* neg, const void* latents, void* out, int64_t n, int dtype,
+                                 float cfg_scale, float dsigma, const float* dev_params, void* stream) {
+    if (n <= 0) return 0;
+    if (dtype != FW_DT_BF16 && dtype != FW_DT_F32) { fw_set_error("fw_cfg_euler_step: bf16 / f32 tensors"); return FW_E_BADARG; }
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == FW_DT_BF16) hipLaunchKernelGGL(cfg_euler_step_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, pos, neg, latents, out, n, cfg_scale, dsigma, dev_params);
+    else hipLaunchKernelGGL(cfg_euler_step_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, pos, neg, latents, out, n, cfg_scale, dsigma, dev_params);
     return (int)hipGetLastError();
 }
 

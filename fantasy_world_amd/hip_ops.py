@@ -27,6 +27,7 @@ SYMBOLS = [
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
     "fw_fp8_quant_rows", "fw_gemm_fp8",
+    "fw_row_sumsq", "fw_qk_prep_tp", "fw_residual_add", "fw_cfg_euler_step",
 ]
 
 _lib = None
@@ -84,6 +85,10 @@ def load_library(path: str = LIB_PATH):
         "fw_add_act": [vp, vp, vp, i64, i32, vp],
         "fw_adaln_rows": [vp, vp, vp, i32, i32, f32, vp],
         "fw_head_activation": [vp, i64, i32, i32, vp, vp, vp],
+        "fw_row_sumsq": [vp, i64, i32, i32, vp, vp],
+        "fw_qk_prep_tp": [vp, i64, i32, i32, i32, vp, f32, i32, vp, i32, f32, vp, i32, vp],
+        "fw_residual_add": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp],
+        "fw_cfg_euler_step": [vp, vp, vp, vp, i64, i32, f32, f32, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -91,7 +96,7 @@ def load_library(path: str = LIB_PATH):
         fn.argtypes = args
     lib.fw_attention_workspace_bytes.restype = i64
     lib.fw_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    if lib.fw_abi_version() != 9:
+    if lib.fw_abi_version() != 10:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib
@@ -267,14 +272,23 @@ class HipOps:
                "fw_layernorm_mod")
         return out
 
-    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0):
+    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
+                ext_sumsq=None, norm_width=None):
         """In place on x [rows, heads*hd] (may be a column slice of a wider buffer).  out_scale: multiplied in before the
-        single bf16 rounding (the engine folds softmax_scale*log2(e) into q: see attention(q_prescaled=True))."""
+        single bf16 rounding (the engine folds softmax_scale*log2(e) into q: see attention(q_prescaled=True)).
+        ext_sumsq / norm_width (norm="rms_full" only): x is a head slice of a wider row whose sum of squares over all
+        `norm_width` channels is supplied per row (tensor parallelism: row_sumsq + all-reduce)."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == heads * hd
-        self._check_dev(x, norm_w, norm_b, table)
+        self._check_dev(x, norm_w, norm_b, table, ext_sumsq)
         tab_rows = 0 if table is None else table.shape[0]
         if table is not None:
             assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1:] == (hd // 2, 2)
+        if ext_sumsq is not None:
+            assert norm == "rms_full" and ext_sumsq.dtype == torch.float32 and ext_sumsq.is_contiguous() and ext_sumsq.numel() == x.shape[0]
+            _check(self.lib.fw_qk_prep_tp(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, _ptr(norm_w), float(eps), ROPE[rope],
+                                          _ptr(table), tab_rows, float(out_scale), ext_sumsq.data_ptr(), int(norm_width),
+                                          self._stream()), "fw_qk_prep_tp")
+            return x
         _check(self.lib.fw_qk_prep(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, NORM[norm], _ptr(norm_w),
                                    _ptr(norm_b), float(eps), ROPE[rope], _ptr(table), tab_rows, float(out_scale),
                                    self._stream()),
@@ -637,6 +651,38 @@ class HipOps:
         """fp8_linear(x, w, b): (xq wq^T) * scale_a + bias -> x.dtype (or fp32)."""
         assert lin.fp8
         return self._linear_fp8(x, lin, out_f32=out_f32)
+
+    # ---- tensor-parallel helpers (fantasy_world_amd/tensor_parallel.py) and the sampler step ------------------------------------
+    def row_sumsq(self, x, out=None):
+        """x bf16 [rows, w] (column slice ok) -> fp32 [rows] sum of squares."""
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+        self._check_dev(x, out)
+        if out is None:
+            out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_row_sumsq(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), self._stream()), "fw_row_sumsq")
+        return out
+
+    def residual_add(self, x, y, bias=None, g1=None, g0=None):
+        """x (fp32 stream, in place) += (y + bias) * g1 + g0; y bf16 / fp32 [rows, C]."""
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and y.shape == x.shape and y.stride(1) == 1
+        self._check_dev(x, y, bias, g1, g0)
+        _check(self.lib.fw_residual_add(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), _dt(y), x.shape[0], x.shape[1],
+                                        _ptr(bias), _ptr(g1), _ptr(g0), self._stream()), "fw_residual_add")
+        return x
+
+    def cfg_euler_step(self, pos, neg, latents, cfg_scale, dsigma, out=None, dev_params=None):
+        """latents + (neg + cfg_scale * (pos - neg)) * dsigma in one launch, bit-identical to the reference's tensor ops
+        (model_wan21.py:318-321, flow_match.py:43-53).  dev_params: device fp32 [2] = (cfg_scale, dsigma) read by the kernel."""
+        assert pos.dtype == neg.dtype == latents.dtype and pos.shape == neg.shape == latents.shape
+        self._check_dev(pos, neg, latents, out, dev_params)
+        pos, neg, latents = pos.contiguous(), neg.contiguous(), latents.contiguous()
+        if out is None:
+            out = torch.empty_like(latents)
+        assert out.is_contiguous() and out.dtype == latents.dtype
+        _check(self.lib.fw_cfg_euler_step(pos.data_ptr(), neg.data_ptr(), latents.data_ptr(), out.data_ptr(), latents.numel(),
+                                          _dt(latents), float(cfg_scale), float(dsigma), _ptr(dev_params), self._stream()),
+               "fw_cfg_euler_step")
+        return out
 
     def cast_act(self, x):
         assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1

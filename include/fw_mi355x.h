@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 9
+#define FW_ABI_VERSION 10
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -160,6 +160,33 @@ int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_t* y, int64
 int fw_qk_prep(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim,
                int norm_mode, const float* norm_w, const float* norm_b, float eps,
                int rope_mode, const float* rope_tab, int tab_rows, float out_scale, void* stream);
+
+/*
+ * Head-sharded tensor parallelism (north_star's partition; fantasy_world_amd/tensor_parallel.py): a rank holds only a column slice
+ * [rows][heads_local*head_dim] of q / k, but the DiT's RMSNorm spans ALL heads (DIT21:135-146,170-171).
+ *   fw_row_sumsq : out[r] = sum_c x[r][c]^2 of the local slice (fp32) -- all-reduced across the ranks by the caller;
+ *   fw_qk_prep_tp: fw_qk_prep(FW_NORM_RMS_FULL) with the row statistic supplied: r = rsqrt(row_sumsq[r] / norm_width + eps),
+ *                  norm_w = the local slice of the weight.
+ *   fw_residual_add: x[r][c] += (y[r][c] + bias[c]) * g1[c] + g0[c] (fp32 stream x; y bf16 or f32; bias / g1 / g0 optional) -- the
+ *                  epilogue of a row-parallel GEMM (o-projection, FFN / MLP second layer) applied AFTER the all-reduce of its
+ *                  partial sums (DIT21:246-251,311-313; VB:73-81).
+ */
+int fw_row_sumsq(const uint16_t* x, int64_t ldx, int rows, int width, float* out, void* stream);
+int fw_qk_prep_tp(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, const float* norm_w, float eps,
+                  int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                  const float* row_sumsq, int norm_width, void* stream);
+int fw_residual_add(float* x, int64_t ldx, const void* y, int64_t ldy, int y_dtype, int rows, int C,
+                    const float* bias, const float* g1, const float* g0, void* stream);
+
+/*
+ * Sampler step on the device: out = latents + (neg + cfg_scale * (pos - neg)) * dsigma -- the CFG combine
+ * (M21:318-319) and FlowMatchScheduler.step (diffsynth_wan21/schedulers/flow_match.py:43-53) in one launch, BIT-identical to the
+ * reference's five PyTorch tensor ops (every intermediate rounded to the tensors' dtype).  n elements, dtype FW_DT_BF16 / FW_DT_F32;
+ * out may alias latents.  dev_params (optional, device float[2] = {cfg_scale, dsigma}) overrides the two host values, so a
+ * captured HIP graph replays with per-step values.
+ */
+int fw_cfg_euler_step(const void* pos, const void* neg, const void* latents, void* out, int64_t n, int dtype,
+                      float cfg_scale, float dsigma, const float* dev_params, void* stream);
 
 /*
  * out[n] = act( sum_k x[k]*W[n,k] + bias[n] ), all fp32, M = 1 (time embeddings:

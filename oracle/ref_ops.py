@@ -108,10 +108,13 @@ class TorchRefOps:
             y = y + shift
         return self._r(y)
 
-    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0):
+    def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
+                ext_sumsq=None, norm_width=None):
         rows = x.shape[0]
         v = x.to(torch.float32)
-        if norm == "rms_full":
+        if norm == "rms_full" and ext_sumsq is not None:         # head slice of a wider row: statistic supplied (fw_qk_prep_tp)
+            v = v * torch.rsqrt(ext_sumsq.view(rows, 1) / float(norm_width) + eps) * norm_w
+        elif norm == "rms_full":
             v = v * torch.rsqrt(v.pow(2).mean(dim=-1, keepdim=True) + eps) * norm_w
         elif norm == "ln_head":
             v = F.layer_norm(v.view(rows, heads, hd), (hd,), norm_w, norm_b, eps).reshape(rows, heads * hd)
@@ -134,6 +137,35 @@ class TorchRefOps:
             v = o.reshape(rows, heads * hd)
         x.copy_(self._r(v * out_scale))
         return x
+
+    def row_sumsq(self, x, out=None):
+        r = x.to(torch.float32).pow(2).sum(dim=-1)
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def residual_add(self, x, y, bias=None, g1=None, g0=None):
+        t = y.to(torch.float32)
+        if bias is not None:
+            t = t + bias
+        if g1 is not None:
+            t = t * g1
+        if g0 is not None:
+            t = t + g0
+        x.add_(t)
+        return x
+
+    def cfg_euler_step(self, pos, neg, latents, cfg_scale, dsigma, out=None, dev_params=None):
+        """The reference's tensor ops, literally (model_wan21.py:318-321, flow_match.py:52)."""
+        if dev_params is not None:
+            cfg_scale, dsigma = float(dev_params[0]), float(dev_params[1])
+        noise_pred = neg + cfg_scale * (pos - neg)
+        r = latents + noise_pred * torch.tensor(dsigma, dtype=torch.float32)
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
 
     def prepare_v(self, v, heads, hd, batch=1):
         return (v, v.shape[0] // batch)

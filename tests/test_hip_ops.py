@@ -494,3 +494,58 @@ def test_assemble_tokens_and_cast(ops, ref):
     assert torch.equal(got.cpu(), want)
     x = torch.randn(37, 5120)
     assert torch.equal(ops.cast_act(x.cuda()).cpu(), x.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------- round 3: sampler step, tensor-parallel helpers
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cfg_euler_step_is_bit_identical_to_the_reference_tensor_ops(ops, dtype):
+    """fw_cfg_euler_step against the reference's own tensor ops on the GPU (model_wan21.py:318-321, flow_match.py:52): every
+    intermediate rounded to the tensors' dtype -> BIT-identical, host values and device parameters alike."""
+    g = torch.Generator().manual_seed(0)
+    shape = (1, 16, 5, 30, 52)
+    pos, neg, lat = (torch.randn(shape, generator=g).to(dtype).cuda() for _ in range(3))
+    for s, ds in ((5.0, -0.004065036773681641), (7.5, -0.09259258210659027), (1.0, 0.0)):
+        noise_pred = neg + s * (pos - neg)
+        want = lat + noise_pred * torch.tensor(ds, dtype=torch.float32)           # sigma_ - sigma is a 0-dim fp32 CPU tensor
+        got = ops.cfg_euler_step(pos, neg, lat, s, ds)
+        assert got.dtype == dtype and torch.equal(got, want), (dtype, s, (got.float() - want.float()).abs().max().item())
+        params = torch.tensor([s, ds], dtype=torch.float32, device="cuda")
+        got2 = ops.cfg_euler_step(pos, neg, lat, 0.0, 0.0, dev_params=params)
+        assert torch.equal(got2, want)
+
+
+def test_row_sumsq_and_qk_prep_with_external_statistics(ops, ref, parity):
+    """Tensor-parallel q/k norm: per-rank partial sums of squares + the row statistic supplied to fw_qk_prep_tp reproduce the
+    full-width RMSNorm + RoPE of fw_qk_prep on every head slice (same arithmetic up to the summation order of the statistic)."""
+    L, H, hd, n = 700, 40, 128, 4
+    x = rnd(L, H * hd, seed=11)
+    w = rnd(H * hd, seed=12, scale=0.2) + 1.0
+    ang = torch.randn(L, hd // 2, generator=torch.Generator().manual_seed(13)).double()
+    tab = torch.stack([ang.cos(), ang.sin()], dim=-1).float()
+    full = ops.qk_prep(bf(x).cuda().clone(), H, hd, norm="rms_full", norm_w=w.cuda(), eps=1e-6, rope="interleaved",
+                       table=tab.cuda(), out_scale=0.1275)
+    xs = bf(x).cuda()
+    wl = H * hd // n
+    parts = [ops.row_sumsq(xs[:, r * wl:(r + 1) * wl]) for r in range(n)]
+    want_ss = x.double().pow(2).sum(-1)
+    tot = torch.stack(parts).sum(0)
+    parity.check("op/row_sumsq", rel_l2(tot, want_ss), 1e-5)
+    for r in range(n):
+        sl = xs[:, r * wl:(r + 1) * wl].clone()
+        ops.qk_prep(sl, H // n, hd, norm="rms_full", norm_w=w[r * wl:(r + 1) * wl].contiguous().cuda(), eps=1e-6, rope="interleaved",
+                    table=tab.cuda(), out_scale=0.1275, ext_sumsq=tot, norm_width=H * hd)
+        # same inputs, same formula; the statistic differs in its last bits -> at most a bf16 ulp on a few elements
+        parity.check(f"op/qk_prep_tp/slice{r}", rel_l2(sl.float(), full[:, r * wl:(r + 1) * wl].float()), 1e-3)
+    want = ref.qk_prep(x.clone(), H, hd, norm="rms_full", norm_w=w, eps=1e-6, rope="interleaved", table=tab, out_scale=0.1275)
+    parity.check("op/qk_prep_tp/vs_fp32", rel_l2(sl.float(), want[:, (n - 1) * wl:]), 4e-3)
+
+
+@pytest.mark.parametrize("ydt", [torch.bfloat16, torch.float32])
+def test_residual_add_epilogue(ops, ref, ydt, parity):
+    rows, C = 515, 1024
+    x, y = rnd(rows, C, seed=21), rnd(rows, C, seed=22)
+    bias, g1, g0 = rnd(C, seed=23, scale=0.1), rnd(C, seed=24), rnd(C, seed=25, scale=0.1)
+    for kw in (dict(), dict(bias=bias), dict(bias=bias, g1=g1), dict(bias=bias, g1=g1, g0=g0)):
+        want = ref.residual_add(x.clone(), y, **kw)
+        got = ops.residual_add(x.clone().cuda(), y.to(ydt).cuda(), **{k: v.cuda() for k, v in kw.items()})
+        parity.check(f"op/residual_add/{ydt}/{len(kw)}", rel_l2(got, want), 1e-6)

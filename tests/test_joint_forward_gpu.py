@@ -553,3 +553,28 @@ def test_b3_hooks_on_hip(parity):
     with torch.no_grad():
         g8 = h8(xl)
     parity.check("hook/hip_linear_fp8", rel_l2(g8.float().reshape(-1, 320), w8), 4e-3)
+
+
+def test_hip_graphed_denoise_step_equals_eager(case_l2):
+    """one whole sampling step captured in a HIP graph (sampler.GraphedDenoiseStep: two forwards +
+    fw_cfg_euler_step, per-step values fed through device buffers) replays to the SAME bits as the eager step, for
+    consecutive steps with different timesteps, and in the merged-CFG form."""
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    from fantasy_world_amd.sampler import FlowMatchScheduler, GraphedDenoiseStep, denoise_step
+    case = case_l2
+    eng = FusionEngine(case.cfg, case.weights.__getitem__, HipOps("cuda:0"))
+    d = {k: (v.cuda().to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else (v.cuda() if torch.is_tensor(v) else v))
+         for k, v in case.inputs.items()}
+    cond = dict(clip_feature=d["clip_feature"], y=d["y"], plucker_fea=d["plucker_fea"], plucker_context_lens=d["plucker_context_lens"])
+    sched = FlowMatchScheduler()
+    sched.set_timesteps(50)
+    for merge in (False, True):
+        lat_e = lat_g = d["x"]
+        g = GraphedDenoiseStep(eng, sched, d["x"], d["context"], d["context_neg"], cond, merge_cfg=merge)
+        for step in (3, 4, 49):
+            lat_e, _ = denoise_step(eng, sched, step, lat_e, d["context"], d["context_neg"], cond, merge_cfg=merge)
+            lat_g = g.step(step, lat_g).clone()
+            torch.cuda.synchronize()
+            assert lat_g.dtype == torch.bfloat16 and torch.equal(lat_g, lat_e), (merge, step)
+        del g
