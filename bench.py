@@ -18,9 +18,12 @@ Other workloads (never the headline; `config.workload` names them):
     --merge-cfg                                 N = 1: both CFG passes of a step as one forward over 2L rows
     --cache-invariants                          step-invariant intermediates cached; off = the
                                                 reference's per-step work
-N > 1 (fantasy_world_amd/parallel.py): the two CFG forwards go to two rank groups, each group sequence-shards its forward (head
-all-to-all for attention) -- strong scaling of ONE sample; the JSON line then carries a `comm` block (bytes each GPU sends per
-step, time the compute stream spent blocked on exchanges).
+N > 1 (fantasy_world_amd/parallel.py): the two CFG forwards go to two rank groups; inside a group the ONE forward is
+    FW_PARALLEL=sp (default)   sequence-sharded, attention through a head all-to-all (parallel.py), or
+    FW_PARALLEL=tp             split by attention heads / FFN columns with all-reduce (tensor_parallel.py: north_star's partition;
+                               FW_TP_REDUCE_DTYPE=bf16|fp32 for the reduced partial sums)
+-- strong scaling of ONE sample; the JSON line then carries a `comm` block (bytes each GPU sends per step per collective kind, time
+the compute stream spent blocked on exchanges), so the two partitions can be A/B-ed with one command each.
 
 Prints ONE JSON line on rank 0 with `roofline` for the dominant kernel (the hd-128 self-attention launch, 41% of the forward's
 FLOPs), `kernels` (live HIP-event averages of the other big launches) and, at N = 1, `cpu_baseline`.
@@ -125,6 +128,12 @@ def dry_run(args):
                 assert torch.equal(back, qkv[:, :heads * hd])            # exchange and its inverse are an identity on q
             full = sh.all_gather_rows(qkv, sh.dit_counts)
             assert full.shape[0] == F * hw
+        if topo.tp is not None:       # FW_PARALLEL=tp: the partial-sum all-reduce and the row all-gather of the bicross fallback
+            tot = topo.tp.all_reduce_async(torch.ones(8)).wait()
+            assert float(tot[0]) == topo.tp.world
+            a, b, counts = topo.tp.rows(13)
+            full = topo.tp.all_gather_rows_async(torch.arange(a, b, dtype=torch.float32).view(-1, 1), counts).wait()
+            assert torch.equal(full.view(-1), torch.arange(13, dtype=torch.float32))
         if topo.cfg_groups == 2:
             pos, neg = topo.gather_cfg(torch.full((4,), float(topo.cfg_rank)))
             assert float(pos[0]) == 0.0 and float(neg[0]) == 1.0
@@ -180,9 +189,9 @@ def main():
     spec = synth.weight_spec(cfg)
     n_experts = (args.experts or 2) if wan22 else 1
     t0 = time.time()
-    engines = [FusionEngine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s), ops, shard=shard,
-                            cache_step_invariants=args.cache_invariants, precision=args.precision,
-                            fp8_attention=args.fp8_attention) for s in range(n_experts)]
+    engines = [parallel.make_engine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s), ops, topo,
+                                    cache_step_invariants=args.cache_invariants, precision=args.precision,
+                                    **({"fp8_attention": True} if args.fp8_attention else {})) for s in range(n_experts)]
     torch.cuda.synchronize()
     t_build = time.time() - t0
     eng = engines[0]
@@ -212,7 +221,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    sp = topo.sp_world
+    sp = topo.group_world          # ranks sharing one forward (sequence-shard or tensor-parallel degree)
     step_id = 0
     for _ in range(args.warmup):
         latents = one_step(step_id, latents)

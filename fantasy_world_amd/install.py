@@ -167,8 +167,13 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
         shard = topo.shard
     pairing = CfgPairing(topo) if topo is not None and topo.cfg_groups == 2 else None
     params = dict(model.named_parameters())
-    engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
-                          cache_step_invariants=cache_step_invariants, precision=precision, shard=shard)
+    if topo is not None and topo.tp is not None:          # north_star's head / FFN-column partition (tensor_parallel.py)
+        from .tensor_parallel import TPFusionEngine
+        engine = TPFusionEngine(cfg, params.__getitem__, ops, topo.tp, heads_cfg=heads_config_from_model(model.vggt),
+                                cache_step_invariants=cache_step_invariants, precision=precision)
+    else:
+        engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
+                              cache_step_invariants=cache_step_invariants, precision=precision, shard=shard)
     watch = _WeightWatch(model)
     engine.weight_watch = watch
     del params

@@ -251,15 +251,26 @@ class SequenceShard:
 
 
 class Topology:
-    """Who this process is: world rank, CFG group (0 = positive prompt, 1 = negative) and the sequence shard inside it."""
+    """Who this process is: world rank, CFG group (0 = positive prompt, 1 = negative) and, inside the group, either the sequence
+    shard (`shard`, mode "sp": head all-to-all, this file) or the tensor-parallel shard (`tp`, mode "tp": head / FFN-column split
+    with all-reduce, tensor_parallel.py -- north_star's partition)."""
 
-    def __init__(self, rank=0, world=1, local=0, cfg_groups=1, cfg_rank=0, shard=None):
+    def __init__(self, rank=0, world=1, local=0, cfg_groups=1, cfg_rank=0, shard=None, tp=None):
         self.rank, self.world, self.local = rank, world, local
-        self.cfg_groups, self.cfg_rank, self.shard = cfg_groups, cfg_rank, shard
+        self.cfg_groups, self.cfg_rank, self.shard, self.tp = cfg_groups, cfg_rank, shard, tp
+
+    @property
+    def mode(self):
+        return "tp" if self.tp is not None else "sp"
 
     @property
     def sp_world(self):
         return 1 if self.shard is None else self.shard.world
+
+    @property
+    def group_world(self):
+        """Ranks that share ONE forward (sequence-shard or tensor-parallel degree)."""
+        return self.tp.world if self.tp is not None else self.sp_world
 
     def describe(self):
         if self.world == 1:
@@ -269,6 +280,8 @@ class Topology:
             parts.append("CFG-parallel x2")
         if self.sp_world > 1:
             parts.append(f"sequence-sharded x{self.sp_world} (head all-to-all + K/V all-gather over RCCL)")
+        if self.tp is not None and self.tp.world > 1:
+            parts.append(f"tensor-parallel x{self.tp.world} (attention heads / FFN columns, all-reduce over RCCL)")
         return " x ".join(parts)
 
     def gather_cfg(self, out):
@@ -280,23 +293,38 @@ class Topology:
         return bufs[0], bufs[self.world // 2]
 
 
-def make_topology(rank, world, local=0, cfg_parallel=True):
+def make_topology(rank, world, local=0, cfg_parallel=True, mode="sp", reduce_dtype=None):
     """Process groups for `world` ranks: two CFG groups of world/2 ranks when world is even (and cfg_parallel), each
-    sequence-sharded internally; otherwise one sequence-sharded group.  Every rank must call this (new_group is collective)."""
+    sharded internally; otherwise one group.  mode "sp" = sequence shard with head exchange (SequenceShard), "tp" = head /
+    FFN-column tensor parallelism with all-reduce (tensor_parallel.TensorShard).  Every rank must call this (new_group is
+    collective)."""
+    if mode not in ("sp", "tp"):
+        raise ValueError(f"mode must be 'sp' or 'tp', got {mode!r}")
     if world == 1:
         return Topology()
+
+    def inner(r, n, group):
+        if n == 1:
+            return {}
+        if mode == "tp":
+            from .tensor_parallel import TensorShard
+            kw = {} if reduce_dtype is None else dict(reduce_dtype=reduce_dtype)
+            return dict(tp=TensorShard(r, n, group, **kw))
+        return dict(shard=SequenceShard(r, n, group))
+
     if cfg_parallel and world % 2 == 0:
         n = world // 2
         groups = [dist.new_group(list(range(g * n, (g + 1) * n))) for g in range(2)]
         cfg_rank, sp_rank = rank // n, rank % n
-        shard = SequenceShard(sp_rank, n, groups[cfg_rank]) if n > 1 else None
-        return Topology(rank, world, local, 2, cfg_rank, shard)
-    return Topology(rank, world, local, 1, 0, SequenceShard(rank, world))
+        return Topology(rank, world, local, 2, cfg_rank, **inner(sp_rank, n, groups[cfg_rank]))
+    return Topology(rank, world, local, 1, 0, **inner(rank, world, None))
 
 
-def init_topology(backend=None, cfg_parallel=True):
-    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) -> Topology."""
+def init_topology(backend=None, cfg_parallel=True, mode=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) -> Topology.
+    mode: "sp" | "tp"; default from $FW_PARALLEL, else "sp"."""
     import os
+    mode = mode or os.environ.get("FW_PARALLEL", "sp")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -310,7 +338,18 @@ def init_topology(backend=None, cfg_parallel=True):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return make_topology(rank, world, local, cfg_parallel)
+    reduce_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(os.environ.get("FW_TP_REDUCE_DTYPE", ""))
+    return make_topology(rank, world, local, cfg_parallel, mode=mode, reduce_dtype=reduce_dtype)
+
+
+def make_engine(cfg, get, ops, topo=None, **kw):
+    """The engine for this rank's place in `topo`: FusionEngine (single GPU / sequence shard) or TPFusionEngine."""
+    if topo is not None and topo.tp is not None:
+        from .tensor_parallel import TPFusionEngine
+        kw.pop("fp8_attention", None)
+        return TPFusionEngine(cfg, get, ops, topo.tp, **kw)
+    from .engine import FusionEngine
+    return FusionEngine(cfg, get, ops, shard=None if topo is None else topo.shard, **kw)
 
 
 def init_from_env(backend=None):

@@ -13,9 +13,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, extra=()):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+def _run(n, extra=(), env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FW_PARALLEL")}
     env["OMP_NUM_THREADS"] = "1"
+    env.update(env_extra or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
                         "--dry-run", *extra], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -49,3 +50,11 @@ def test_bench_refuses_mismatched_world(monkeypatch):
                        text=True, timeout=120, env=env, cwd=ROOT)
     # WORLD_SIZE is set, so no self-launch; the dry run reports the world it really has
     assert p.returncode == 0 and '"n_gpus": 1' in p.stdout
+
+
+def test_bench_tensor_parallel_mode_by_environment():
+    """FW_PARALLEL=tp selects north_star's partition (2 CFG groups x TP n/2) with the same command line."""
+    out = _run(8, env_extra={"FW_PARALLEL": "tp"})
+    par = out["config"]["parallelism"]
+    assert "CFG-parallel x2" in par and "tensor-parallel x4" in par and "sequence-sharded" not in par
+    assert {"all_reduce", "all_gather_rows", "all_gather_cfg"} <= set(out["comm"]["by_kind"])
