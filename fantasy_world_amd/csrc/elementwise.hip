@@ -84,8 +84,8 @@ constexpr int LNW_MAXV = 20;
 // The normalise / modulate arithmetic of BOTH LayerNorm wave kernels, spelled out operation by operation (no contraction, no
 // reassociation): u = (v - mean) * rstd;  [u = u * w (+ b)];  u = fma(u, scale, u) = u * (1 + scale) in one rounding;  u = u + shift.
 // A sequence shard (few rows per rank: one-wave-per-row kernel) and the unsharded forward (LDS-staged kernel) must agree bit for bit.
-__device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, const float* w, const float* b, bool has_scale,
-                                             f32x4_t sc, bool has_shift, f32x4_t sh, int c0) {
+__device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, bool has_w, f32x4_t w4, bool has_b, f32x4_t b4,
+                                             bool has_scale, f32x4_t sc, bool has_shift, f32x4_t sh) {
 #pragma clang fp contract(off)
 #pragma clang fp reassociate(off)
     f32x4_t t;
@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, 
     for (int j = 0; j < 4; ++j) {
         float u = v[j] - mean;
         u = u * rstd;
-        if (w) { u = u * w[c0 + j]; if (b) u = u + b[c0 + j]; }
+        if (has_w) { u = u * w4[j]; if (has_b) u = u + b4[j]; }
         if (has_scale) u = __builtin_fmaf(u, sc[j], u);
         if (has_shift) u = u + sh[j];
         t[j] = u;
@@ -139,25 +139,32 @@ __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __r
     for (int i = 0; i < VPL; ++i) {
         const int c0 = (lane + 64 * i) * 4;
         const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-        const f32x4_t t = ln_finish(v[i], mean, rstd, w, b, scale != nullptr, scale ? *(const f32x4_t*)(scale + c0) : zero,
-                                    shift != nullptr, shift ? *(const f32x4_t*)(shift + c0) : zero, c0);
+        const f32x4_t t = ln_finish(v[i], mean, rstd, w != nullptr, w ? *(const f32x4_t*)(w + c0) : zero,
+                                    w != nullptr && b != nullptr, (w && b) ? *(const f32x4_t*)(b + c0) : zero,
+                                    scale != nullptr, scale ? *(const f32x4_t*)(scale + c0) : zero,
+                                    shift != nullptr, shift ? *(const f32x4_t*)(shift + c0) : zero);
         u32x2_t out = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
         *(u32x2_t*)(yr + c0) = out;
     }
 }
 
-// The hot case -- AdaLN-modulated LayerNorm of the fp32 DiT stream, no affine weights (wan_video_dit.py:301-310; 290 launches per
-// step) -- with the two modulation vectors staged ONCE per work-group in LDS and the work-groups walking the rows: the kernel above
+// Parameter vectors staged ONCE per work-group in LDS, work-groups walking the rows.  The hot case is the AdaLN-modulated LayerNorm
+// of the fp32 DiT stream without affine weights (wan_video_dit.py:301-310; 290 launches per step): the one-wave-per-row kernel above
 // re-reads 40 KiB of scale / shift through the texture path for every 20 KiB row it normalises (60 vector loads per row instead of
-// 20), and measures 4.7 TB/s where torch's plain fp32 -> bf16 cast reaches 5.85 (tools/probes/stream_bw.py).
-template <int VPL>
-__global__ __launch_bounds__(256) void layernorm_mod_lds_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
-                                                                int64_t ldy, int rows, int C, const float* __restrict__ scale,
-                                                                const float* __restrict__ shift, float eps) {
-    __shared__ f32x4_t smA[VPL * 64], smB[VPL * 64];          // scale, shift
+// 20) and measures 4.7 TB/s where torch's plain fp32 -> bf16 cast reaches 5.85 (tools/probes/stream_bw.py).  Round 3 (kernel trace
+// of the bench at HEAD): the same disease on the AFFINE forms -- DiT norm3 (w, b; 426 us per launch against 189 us for the modulated
+// form of the same rows) and the VGGT norm1 / norm2 (w, b [, scale, shift] on 4 KiB rows: 16 KiB of parameters per row, 1.95 TB/s)
+// -- so AFF / MOD are template flags and every combination stages what it uses.  Same ln_finish arithmetic as the wave kernel:
+// bit-identical results.
+template <int VPL, bool AFF, bool MOD>
+__global__ __launch_bounds__(256) void layernorm_lds_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
+                                                            int64_t ldy, int rows, int C, const float* __restrict__ w,
+                                                            const float* __restrict__ b, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float eps) {
+    __shared__ f32x4_t smW[AFF ? VPL * 64 : 1], smBi[AFF ? VPL * 64 : 1], smA[MOD ? VPL * 64 : 1], smB[MOD ? VPL * 64 : 1];
     for (int i = threadIdx.x; i < VPL * 64; i += 256) {
-        smA[i] = *(const f32x4_t*)(scale + i * 4);
-        smB[i] = *(const f32x4_t*)(shift + i * 4);
+        if (AFF) { smW[i] = *(const f32x4_t*)(w + i * 4); smBi[i] = *(const f32x4_t*)(b + i * 4); }
+        if (MOD) { smA[i] = *(const f32x4_t*)(scale + i * 4); smB[i] = *(const f32x4_t*)(shift + i * 4); }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -180,7 +187,9 @@ __global__ __launch_bounds__(256) void layernorm_mod_lds_kernel(const float* __r
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = lane + 64 * i;
-            const f32x4_t t = ln_finish(v[i], mean, rstd, nullptr, nullptr, true, smA[c], true, smB[c], c * 4);
+            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t t = ln_finish(v[i], mean, rstd, AFF, AFF ? smW[c] : zero, AFF, AFF ? smBi[c] : zero,
+                                        MOD, MOD ? smA[c] : zero, MOD, MOD ? smB[c] : zero);
             u32x2_t out = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
             *(u32x2_t*)(yr + c * 4) = out;
         }
@@ -190,11 +199,17 @@ __global__ __launch_bounds__(256) void layernorm_mod_lds_kernel(const float* __r
 template <bool XF32>
 static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C,
                            const float* w, const float* b, const float* scale, const float* shift, float eps) {
-    if (XF32 && C == 5120 && !w && !b && scale && shift && rows >= 4096) {
-        // 4 work-groups of 40 KiB LDS per CU, each walking rows
-        const int wgs = min((rows + 3) / 4, 256 * 4);
-        hipLaunchKernelGGL(layernorm_mod_lds_kernel<20>, dim3(wgs), dim3(256), 0, st, (const float*)x, ldx, y, ldy, rows, C, scale, shift, eps);
-        return true;
+    if (XF32 && rows >= 4096 && (C == 5120 || C == 1024)) {
+        // parameters staged in LDS (20 KiB per vector at C = 5120: 4 work-groups per CU; 4 KiB at C = 1024: 8 per CU), rows walked
+        const bool aff = w && b, mod = scale && shift;
+        const bool pure = (aff || (!w && !b)) && (mod || (!scale && !shift));       // no half-specified pairs on this path
+        const int wgs = min((rows + 3) / 4, 256 * (C == 5120 ? 4 : 8));
+#define FW_LN_LDS(V, A, M) do { hipLaunchKernelGGL((layernorm_lds_kernel<V, A, M>), dim3(wgs), dim3(256), 0, st, (const float*)x, ldx, y, ldy, rows, C, w, b, scale, shift, eps); return true; } while (0)
+        if (pure && (aff || mod)) {
+            if (C == 5120) { if (aff && mod) FW_LN_LDS(20, true, true); else if (aff) FW_LN_LDS(20, true, false); else FW_LN_LDS(20, false, true); }
+            else { if (aff && mod) FW_LN_LDS(4, true, true); else if (aff) FW_LN_LDS(4, true, false); else FW_LN_LDS(4, false, true); }
+        }
+#undef FW_LN_LDS
     }
     const dim3 grid((rows + 3) / 4), block(256);
 #define FW_LN_CASE(V) case V: hipLaunchKernelGGL((layernorm_mod_wave_kernel<XF32, V>), grid, block, 0, st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps); return true;
@@ -798,6 +813,8 @@ template <bool BF16>
 __global__ __launch_bounds__(256) void cfg_euler_step_kernel(const void* __restrict__ posv, const void* __restrict__ negv,
                                                              const void* __restrict__ latv, void* __restrict__ outv, int64_t n,
                                                              float s, float ds, const float* __restrict__ params) {
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     if (params) { s = params[0]; ds = params[1]; }
@@ -812,8 +829,16 @@ __global__ __launch_bounds__(256) void cfg_euler_step_kernel(const void* __restr
         ((uint16_t*)outv)[i] = f32_to_bf16_bits(__fadd_rn(x, m));
     } else {
         p = ((const float*)posv)[i]; q = ((const float*)negv)[i]; x = ((const float*)latv)[i];
-        const float np = __fadd_rn(q, __fmul_rn(__fsub_rn(p, q), s));
-        ((float*)outv)[i] = __fadd_rn(x, __fmul_rn(np, ds));
+        // five separately rounded fp32 operations, as five PyTorch kernels compute them (-ffast-math would contract them into FMAs)
+        float d = p - q;
+        asm volatile("" : "+v"(d));
+        float e = d * s;
+        asm volatile("" : "+v"(e));
+        float np = q + e;
+        asm volatile("" : "+v"(np));
+        float m = np * ds;
+        asm volatile("" : "+v"(m));
+        ((float*)outv)[i] = x + m;
     }
 }
 

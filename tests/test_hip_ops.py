@@ -359,6 +359,27 @@ def test_layernorm_mod_large_row_kernel_is_bit_identical_to_the_small_one(ops, r
     parity.check(f"op/{request.node.name}/0", rel_l2(big.float(), want), 4e-3)
 
 
+@pytest.mark.parametrize("C,affine,mod", [(5120, True, False), (5120, True, True), (1024, True, True), (1024, True, False),
+                                          (1024, False, True)])
+def test_layernorm_lds_staged_forms_are_bit_identical_to_the_row_kernel(ops, ref, C, affine, mod, parity, request):
+    """Round 3: every parameterised LayerNorm form of the forward stages its vectors in LDS from 4096 rows on (DiT norm3 = affine
+    only; VGGT norm1 = affine + modulation, norm2 = affine only).  Same ln_finish arithmetic as the one-wave-per-row kernel: a call
+    over 4100 rows equals two calls over 2050 rows BIT FOR BIT (a sequence shard runs the small kernel), and matches fp32."""
+    rows = 4100
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(rows, C, generator=g) * 2 + 0.3
+    w, b = ((1 + 0.1 * torch.randn(C, generator=g)), 0.1 * torch.randn(C, generator=g)) if affine else (None, None)
+    sc, sh = (0.3 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)) if mod else (None, None)
+    want = ref.layernorm(x, w, b, sc, sh, 1e-5)
+    cu = lambda t: None if t is None else t.cuda()
+    xd = x.cuda()
+    kw = dict(w=cu(w), b=cu(b), scale=cu(sc), shift=cu(sh), eps=1e-5)
+    big = ops.layernorm(xd, **kw)
+    halves = torch.cat([ops.layernorm(xd[:2050].contiguous(), **kw), ops.layernorm(xd[2050:].contiguous(), **kw)], dim=0)
+    assert torch.equal(big, halves)
+    parity.check(f"op/{request.node.name}/0", rel_l2(big.float(), want), 4e-3)
+
+
 def test_qk_prep_rms_full_rope3d(ops, ref, parity, request):
     """DiT q/k: RMSNorm over the full 5120 width (DIT21:170-171) + interleaved 3-D RoPE (DIT21:97-102)."""
     from fantasy_world_amd import rope

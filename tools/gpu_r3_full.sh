@@ -4,7 +4,7 @@
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; TAG=${TAG:-r3}; mkdir -p $O; cd $R
 rm -f $O/parity_gpu.json
-timeout 1800 python -m pytest tests -m gpu -q -x > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu_$TAG.log
+timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu_$TAG.log 2>&1; echo "pytest exit $?" >> $O/pytest_gpu_$TAG.log
 grep -v "Warning\|warn\|amp\.\|super()" $O/pytest_gpu_$TAG.log | tail -25
 timeout 1200 python bench.py --steps 2 --warmup 1 --hip-graph > $O/bench_$TAG.log 2>&1; tail -1 $O/bench_$TAG.log | cut -c1-400; tail -1 $O/bench_$TAG.log | grep -o '"hip_graph".*' | cut -c1-600
 if [ -z "$SKIP_PROF" ]; then
