@@ -294,7 +294,7 @@ def main():
     headline = (not wan22 and args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
                 and args.precision == "bf16")
     if headline and sp == 1:
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                     traffic = float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])

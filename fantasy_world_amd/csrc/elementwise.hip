@@ -101,6 +101,25 @@ __device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, 
     return t;
 }
 
+// Row statistics of BOTH LayerNorm wave kernels, with the summation order pinned (no reassociation under -ffast-math): the LDS-staged
+// kernel (unsharded forward) and the one-wave-per-row kernel (a sequence shard's few rows) must produce the same mean / rstd bits.
+// (Round 3: with VPL = 4 the compiler associated the two kernels' sums differently -- caught by the sharded-vs-unsharded bit test.)
+template <int VPL>
+__device__ __forceinline__ void ln_stats(const f32x4_t (&v)[VPL], int C, float eps, float& mean, float& rstd) {
+#pragma clang fp contract(off)
+#pragma clang fp reassociate(off)
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s = s + ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q = q + d * d; }
+    rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+}
+
 template <bool XF32, int VPL>
 __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __restrict__ xin, int64_t ldx,
                                                                  uint16_t* __restrict__ y, int64_t ldy, int rows, int C,
@@ -124,16 +143,8 @@ __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __r
             v[i][2] = __uint_as_float(raw[1] << 16); v[i][3] = __uint_as_float(raw[1] & 0xffff0000u);
         }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float mean, rstd;
+    ln_stats<VPL>(v, C, eps, mean, rstd);
     uint16_t* yr = y + (int64_t)row * ldy;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -173,16 +184,8 @@ __global__ __launch_bounds__(256) void layernorm_lds_kernel(const float* __restr
         const float* xr = x + (int64_t)row * ldx;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) v[i] = *(const f32x4_t*)(xr + (lane + 64 * i) * 4);
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        const float mean = wave_sum(s) / (float)C;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < VPL; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
-        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float mean, rstd;
+        ln_stats<VPL>(v, C, eps, mean, rstd);
         uint16_t* yr = y + (int64_t)row * ldy;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {

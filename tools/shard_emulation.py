@@ -1,8 +1,10 @@
 #!/usr/bin/env python
-"""Per-rank compute time of a sequence-sharded forward, measured on ONE GPU: the collectives of SequenceShard are replaced
-by local stand-ins that return tensors of the right shape (own rows tiled), so every kernel runs at exactly the shapes a rank
-of an n-way group sees (L/n rows for GEMMs and norms, L rows x H/n heads for attention).  compute-only scaling bound =
-t(1) / t(n); communication is NOT included (it is on top: see DESIGN.md section 6 for the byte counts)."""
+"""Per-rank compute time of a sharded forward, measured on ONE GPU: the collectives are replaced by local stand-ins that return
+tensors of the right shape, so every kernel runs at exactly the shapes a rank of an n-way group sees.
+  --sp 1,2,4   sequence shard (L/n rows for GEMMs and norms, L rows x H/n heads for attention; parallel.py)
+  --tp 2,4,8   north_star's head / FFN-column tensor parallelism (all L rows, H/n heads, 1/n of the FFN columns, replicated norms
+               and fw_residual_add epilogues; tensor_parallel.py), all-reduce = no-op
+compute-only scaling bound = t(1) / t(n); communication is NOT included (DESIGN.md section 6 has the byte counts of both)."""
 import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,9 +39,25 @@ class LocalShard(SequenceShard):
         return Ready(o[:rows].repeat(1, self.world).contiguous())
 
 
+def local_tensor_shard(n):
+    from fantasy_world_amd.tensor_parallel import TensorShard
+
+    class LocalTensorShard(TensorShard):
+        def all_reduce_async(self, t, kind="all_reduce"):
+            return Ready(t)
+
+        def all_gather_rows_async(self, t, counts):
+            total = sum(counts)
+            reps = (total + t.shape[0] - 1) // t.shape[0]
+            return Ready(t.repeat(reps, 1)[:total].contiguous())
+
+    return LocalTensorShard(0, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sp", default="1,2,4,8")
+    ap.add_argument("--tp", default="", help="tensor-parallel degrees to emulate after the sequence-shard ones, e.g. 2,4,8")
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--host-cost", action="store_true",
                     help="also run the SAME full-depth engine (same launch count, same Python path) on a tiny latent grid, where "
@@ -56,9 +74,14 @@ def main():
                 plucker_context_lens=ins["plucker_context_lens"])
     t = torch.tensor([500.0], device=dev, dtype=torch.bfloat16)
     base = None
-    for n in [int(v) for v in args.sp.split(",")]:
-        shard = None if n == 1 else LocalShard(0, n)
-        eng = FusionEngine(cfg, lambda nm: synth.make_param(nm, spec[nm][0], spec[nm][1], device=dev), ops, shard=shard)
+    plan = [("sp", int(v)) for v in args.sp.split(",") if v] + [("tp", int(v)) for v in args.tp.split(",") if v]
+    for kind, n in plan:
+        get = lambda nm: synth.make_param(nm, spec[nm][0], spec[nm][1], device=dev)
+        if kind == "tp":
+            from fantasy_world_amd.tensor_parallel import TPFusionEngine
+            eng = TPFusionEngine(cfg, get, ops, local_tensor_shard(n))
+        else:
+            eng = FusionEngine(cfg, get, ops, shard=None if n == 1 else LocalShard(0, n))
         eng.joint_forward(ins["x"], t, ins["context"], **cond)
         torch.cuda.synchronize()
         t0 = time.time()
@@ -67,7 +90,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.time() - t0) / args.iters
         base = base or dt
-        print(f"sp={n}: one forward (rank 0 shapes) {dt*1e3:8.1f} ms   compute-only speed-up vs sp=1: {base/dt:5.2f}x   "
+        print(f"{kind}={n}: one forward (rank 0 shapes) {dt*1e3:8.1f} ms   compute-only speed-up vs sp=1: {base/dt:5.2f}x   "
               f"(x{2 if True else 1} CFG groups -> {2*n} GPUs: step = {dt*1e3:.0f} ms + comm)", flush=True)
         if args.host_cost:
             tiny = synth.make_inputs(cfg, 8, 8, 8, seed=1, device=dev, dtype=torch.bfloat16)      # 8 latent frames: >= 1 per rank
@@ -81,7 +104,7 @@ def main():
                 eng.joint_forward(tiny["x"], t, tiny["context"], **tc)
             torch.cuda.synchronize()
             th = (time.time() - t0) / 5
-            print(f"        host enqueue cost of one forward at sp={n} (tiny grid, launch-bound): {th*1e3:6.1f} ms = "
+            print(f"        host enqueue cost of one forward at {kind}={n} (tiny grid, launch-bound): {th*1e3:6.1f} ms = "
                   f"{100*th/dt:4.1f} % of the full-size forward's {dt*1e3:.0f} ms", flush=True)
         del eng
         torch.cuda.empty_cache()
