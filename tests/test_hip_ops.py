@@ -210,6 +210,25 @@ def test_attention_matches_softmax_reference(attn_variant, ops, ref, heads, hd, 
     parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
+@pytest.mark.parametrize("heads,hd,Lq,Lk", [(16, 64, 256 * 16 + 97, 256 * 16 + 97), (12, 96, 256 * 64 + 97, 2100)])
+def test_attention_split_kv_plan_does_not_depend_on_the_batch(ops, heads, hd, Lq, Lk):
+    """Round-2 advisor finding: the number of key runs of the split-KV tail came from 256 / (heads * batch), so the merged CFG pass
+    (batch 2) merged a tail row's runs in another order than two separate forwards (batch 1) -- joint_forward_pair was not
+    bit-identical to two joint_forward calls at shapes that take the split route (VGGT global attention at L2 = 32865).  The plan
+    is now a function of (heads, Lq, Lk) only: two samples stacked along the batch equal two separate calls BIT FOR BIT, tail rows
+    included."""
+    assert ops.lib.fw_attention_workspace_bytes(1, heads, hd, Lq, Lk) > 0
+    assert ops.lib.fw_attention_workspace_bytes(2, heads, hd, Lq, Lk) == 2 * ops.lib.fw_attention_workspace_bytes(1, heads, hd, Lq, Lk)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    D = heads * hd
+    q = (torch.randn(2 * Lq, D, device="cuda", generator=g) * ops.q_scale(hd)).to(torch.bfloat16)
+    k = torch.randn(2 * Lk, D, device="cuda", generator=g).to(torch.bfloat16)
+    v = torch.randn(2 * Lk, D, device="cuda", generator=g).to(torch.bfloat16)
+    both = ops.attention(q, k, v, heads, hd, batch=2, q_prescaled=True)
+    one = [ops.attention(q[i * Lq:(i + 1) * Lq], k[i * Lk:(i + 1) * Lk], v[i * Lk:(i + 1) * Lk], heads, hd, q_prescaled=True) for i in range(2)]
+    assert torch.equal(both[:Lq], one[0]) and torch.equal(both[Lq:], one[1])
+
+
 @pytest.mark.parametrize("heads,hd,Lq,Lk", [(12, 96, 256 * 64 + 97, 1100), (16, 64, 256 * 16 + 30, 2048), (40, 128, 256 * 32 + 5, 1030)])
 def test_attention_split_kv_tail(ops, ref, heads, hd, Lq, Lk, parity, request):
     """Tail q-block through split-KV (the launcher takes the route when the tail work-groups would cost an extra round of the
