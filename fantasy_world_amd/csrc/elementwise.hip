@@ -86,16 +86,19 @@ constexpr int LNW_MAXV = 20;
 // A sequence shard (few rows per rank: one-wave-per-row kernel) and the unsharded forward (LDS-staged kernel) must agree bit for bit.
 __device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, bool has_w, f32x4_t w4, bool has_b, f32x4_t b4,
                                              bool has_scale, f32x4_t sc, bool has_shift, f32x4_t sh) {
-#pragma clang fp contract(off)
-#pragma clang fp reassociate(off)
+    // Every fusion is spelled out (explicit fma) and every place where the back end could still contract or reassociate under
+    // -ffast-math (it honours the function-level unsafe-fp-math attribute, not the per-statement pragmas) is fenced by an empty asm:
+    // the two LayerNorm kernels must emit the same arithmetic whatever their surrounding code looks like.
     f32x4_t t;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float u = v[j] - mean;
+        asm volatile("" : "+v"(u));
         u = u * rstd;
-        if (has_w) { u = u * w4[j]; if (has_b) u = u + b4[j]; }
+        asm volatile("" : "+v"(u));
+        if (has_w) u = has_b ? __builtin_fmaf(u, w4[j], b4[j]) : u * w4[j];
         if (has_scale) u = __builtin_fmaf(u, sc[j], u);
-        if (has_shift) u = u + sh[j];
+        if (has_shift) { asm volatile("" : "+v"(u)); u = u + sh[j]; }
         t[j] = u;
     }
     return t;
@@ -106,18 +109,32 @@ __device__ __forceinline__ f32x4_t ln_finish(f32x4_t v, float mean, float rstd, 
 // (Round 3: with VPL = 4 the compiler associated the two kernels' sums differently -- caught by the sharded-vs-unsharded bit test.)
 template <int VPL>
 __device__ __forceinline__ void ln_stats(const f32x4_t (&v)[VPL], int C, float eps, float& mean, float& rstd) {
-#pragma clang fp contract(off)
-#pragma clang fp reassociate(off)
+    // pinned order: chunk sums (a + b) + (c + d) accumulated left to right, squares by explicit fma, 1 / C as one reciprocal used
+    // by both statistics; the asm fences keep the back end from re-associating / contracting across statements
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) s = s + ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3]));
-    mean = wave_sum(s) / (float)C;
+    for (int i = 0; i < VPL; ++i) {
+        float a = v[i][0] + v[i][1], b = v[i][2] + v[i][3];
+        asm volatile("" : "+v"(a), "+v"(b));
+        float c = a + b;
+        asm volatile("" : "+v"(c));
+        s = s + c;
+        asm volatile("" : "+v"(s));
+    }
+    float inv_c = 1.0f / (float)C;
+    asm volatile("" : "+v"(inv_c));
+    mean = wave_sum(s) * inv_c;
+    asm volatile("" : "+v"(mean));
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q = q + d * d; }
-    rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        for (int j = 0; j < 4; ++j) {
+            float d = v[i][j] - mean;
+            asm volatile("" : "+v"(d));
+            q = __builtin_fmaf(d, d, q);
+        }
+    rstd = rsqrtf(__builtin_fmaf(wave_sum(q), inv_c, eps));
 }
 
 template <bool XF32, int VPL>

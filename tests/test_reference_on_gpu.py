@@ -73,16 +73,17 @@ def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
     torch.cuda.synchronize()
     uninstall(model)
     assert got16.dtype == ref16.dtype == torch.bfloat16
-    e_ref16, e_got16 = rel_l2(ref16.float(), want), rel_l2(got16.float(), want)
-    parity.note("ref_on_gpu/generate_video/latents_reference_bf16_autocast_vs_ref_fp32", e_ref16)
-    print(f"latents vs reference fp32: HIP path {e_lat:.2e} (fp32 I/O), {e_got16:.2e} (bf16 I/O); reference's own bf16 autocast {e_ref16:.2e}")
+    e_ref16_vs_fp32, e_16 = rel_l2(ref16.float(), want), rel_l2(got16.float(), ref16.float())
+    parity.note("ref_on_gpu/generate_video/latents_reference_bf16_config_vs_reference_fp32", e_ref16_vs_fp32)
+    print(f"latents: HIP vs reference, fp32 I/O {e_lat:.2e}; HIP vs reference, both in the bf16 inference configuration {e_16:.2e}; "
+          f"reference bf16 configuration vs reference fp32 {e_ref16_vs_fp32:.2e}")
     # Two sampling steps: the CFG combine neg + 5 (pos - neg) multiplies a forward's relative error by ~sqrt(5^2 + 4^2) = 6.4 and the
-    # 2-step schedule's last update has sigma 0.83, so the latents carry a few 1e-2 of the forwards' 2.7e-3 -- in the reference's own
-    # bf16 path as much as here.  Physical bound 4e-2; the claim that matters: the drop-in is not further from the fp32 truth than
-    # the reference's own bf16 inference configuration is (+ one bf16 rounding of the latents).
+    # 2-step schedule's last update has sigma 0.83, so the latents carry ~1e-2 of the forwards' 2.7e-3.  Like against like: fp32 I/O
+    # against the reference in fp32; the bf16 inference configuration against the reference in ITS bf16 configuration (which
+    # rounds the timestep to bf16, model_wan21.py:292-293: 833.3 -> 832, worth 1e-1 on the latents against the fp32 run -- a
+    # property of the reference, reproduced, not an error of either side).
     parity.check("ref_on_gpu/generate_video/latents_hip_vs_ref_fp32", e_lat, 4e-2)
-    parity.check("ref_on_gpu/generate_video/latents_hip_bf16_config_vs_ref_fp32", e_got16, 4e-2)
-    assert e_lat < 1.5 * e_ref16 + 4e-3 and e_got16 < 1.5 * e_ref16 + 4e-3, (e_lat, e_got16, e_ref16)
+    parity.check("ref_on_gpu/generate_video/latents_hip_vs_ref_both_bf16_config", e_16, 4e-2)
     # the prediction of the reference on a GPU is computed under ITS bf16 autocast (vggt.py:136): both sides carry bf16 noise, on
     # top of the latents' divergence above
     for k in PRED_KEYS:
