@@ -10,6 +10,10 @@ src = sys.argv[1]
 rows = json.load(open(src))
 bounds = {}
 for name, row in rows.items():
+    # ref_on_gpu/*: comparisons against PyTorch-ROCm / hipBLASLt kernels (the real reference on the GPU box) -- their algorithm
+    # selection is not ours to pin, so they keep the tests' physical bounds only
+    if name.startswith("ref_on_gpu/"):
+        continue
     if isinstance(row, dict) and "measured" in row:
         # 1.5 x measured; a floor keeps exact (0.0) or near-exact comparisons from becoming `< 0`
         bounds[name] = max(1.5 * row["measured"], 1e-7)
