@@ -676,6 +676,11 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     constexpr bool AB_NOEXP = (VAR & 4) != 0, AB_NODS = (VAR & 8) != 0, AB_NODMA = (VAR & 16) != 0;
     constexpr bool AB_NOPV = (VAR & 32) != 0, AB_NOQK = false;
     constexpr bool PAIR = (VAR & 128) != 0;   // one barrier per TWO 64-key tiles (FW_ATTN_VAR 160 + bits)
+    // Round 3: the tile loop unrolled by the ring depth, so the ring slot of every K / Vt fragment read is a compile-time constant
+    // and folds into the ds_read's immediate offset.  With run-time slots the loop spent 27 of its 108 VALU instructions per 64-key
+    // tile (hd 128) on LDS addresses (16 v_add_u32, 9 v_or_b32, 2 v_lshl_add) -- and VALU cycles ADD to the matrix cycles on this
+    // SIMD.
+    constexpr bool UNR = (VAR & 64) != 0;
     constexpr int NS = (VAR & 2) ? 2 : 1;     // 32-row sub-blocks per wave: 2 = one wave per SIMD owning 64 query rows
     constexpr int NW = 8 / NS;                // waves per work-group (256 query rows either way)
     constexpr int NP = 16 / NW;               // 1 KiB K pieces / Vt pieces each wave requests per tile
@@ -816,8 +821,9 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     // the magnitude, so there is nothing to rescale.  A half-row sum beyond 2^96 (or a NaN) only raises `bad`; such a wave
     // recomputes its rows with the exact recurrence after the loop.  The loop body therefore has no data-dependent branch.
     // Every K / Vt fragment feeds the MFMAs of all NS sub-blocks (NS = 2 halves the LDS reads per MFMA).
-    auto half = [&](f32x16_t (&cur)[NS], f32x16_t (&nxt)[NS], int t, auto hf_tag, auto next_tag, auto next2_tag, auto mask_tag)
-                    __attribute__((always_inline)) {
+    auto half = [&](f32x16_t (&cur)[NS], f32x16_t (&nxt)[NS], int t, auto slot_tag, auto hf_tag, auto next_tag, auto next2_tag,
+                    auto mask_tag) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_tag)::value;        // ring slot of tile t when known at compile time, -1 = t & (ARING - 1)
         constexpr int hf = decltype(hf_tag)::value;
         constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value, MASK = decltype(mask_tag)::value;
         if (MASK) {
@@ -830,7 +836,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
                         if (kbase + (r & 3) + 8 * (r >> 2) >= Lk) cur[sb][r] = -1.0e30f;
             }
         }
-        const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+        const char* vb = smem + (SL >= 0 ? SL : (t & (ARING - 1))) * VT_TILE_BYTES;
         // ---- stage A: QK^T of half u+1 (fr = its K fragments), softmax of half u, Vt fragments of half u into the freed registers
         float ls[NS];
 #pragma unroll
@@ -878,7 +884,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
             l_run[sb] += ls[sb];
         }
         // ---- stage B: PV of half u, K fragments of half u+2 behind the MFMAs
-        const char* kb = smem + ((t + 1) & (ARING - 1)) * K_TILE_BYTES + hf * 32 * 256;      // half u+2 = tile t+1, same block
+        const char* kb = smem + (SL >= 0 ? ((SL + 1) & (ARING - 1)) : ((t + 1) & (ARING - 1))) * K_TILE_BYTES + hf * 32 * 256;      // half u+2 = tile t+1, same block
 #pragma unroll
         for (int i = 0; i < HF; ++i) {
             const int ks2 = i / DB, d = i % DB;
@@ -907,15 +913,16 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     using H1 = std::integral_constant<int, 1>;
     // one 64-key tile.  The ring slot of K(t+3) held K(t-1) and that of Vt(t+2) held Vt(t-2), both dead; near the end the
     // requests are clamped to the last tile (they land in slots nobody reads) so the wait count stays a constant.
-    auto tile = [&](int t, auto last_tag) __attribute__((always_inline)) {
+    using SR = std::integral_constant<int, -1>;
+    auto tile = [&](int t, auto slot_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
         using NotLast = std::integral_constant<bool, !LAST>;
-        half(sA, sB, t, H0{}, T_{}, NotLast{}, last_tag);
+        half(sA, sB, t, slot_tag, H0{}, T_{}, NotLast{}, last_tag);
         if (!LAST && !AB_NODMA) {
             issue_k(min(t + 3, nt - 1), t + 3);
             issue_v(min(t + 2, nt - 1), t + 2);
         }
-        half(sB, sA, t, H1{}, NotLast{}, NotLast{}, last_tag);
+        half(sB, sA, t, slot_tag, H1{}, NotLast{}, NotLast{}, last_tag);
         if (!LAST && !AB_NODMA) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fw_await_vm<2 * NP>();
@@ -981,25 +988,37 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
             issue_k(min(t + 4, nt - 1), t + 4);
             issue_v(min(t + 2, nt - 1), t + 2);
             issue_v(min(t + 3, nt - 1), t + 3);
-            half(sA, sB, t, H0{}, T_{}, T_{}, F_{});
-            half(sB, sA, t, H1{}, T_{}, T_{}, F_{});
-            half(sA, sB, t + 1, H0{}, T_{}, T_{}, F_{});
-            half(sB, sA, t + 1, H1{}, T_{}, T_{}, F_{});
+            half(sA, sB, t, SR{}, H0{}, T_{}, T_{}, F_{});
+            half(sB, sA, t, SR{}, H1{}, T_{}, T_{}, F_{});
+            half(sA, sB, t + 1, SR{}, H0{}, T_{}, T_{}, F_{});
+            half(sB, sA, t + 1, SR{}, H1{}, T_{}, T_{}, F_{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             fw_await_vm<0>();
             FW_ABARRIER();
         }
         if (t + 1 < nt) {                     // a non-last tile whose data the last pair already brought in
-            half(sA, sB, t, H0{}, T_{}, T_{}, F_{});
-            half(sB, sA, t, H1{}, T_{}, T_{}, F_{});
+            half(sA, sB, t, SR{}, H0{}, T_{}, T_{}, F_{});
+            half(sB, sA, t, SR{}, H1{}, T_{}, T_{}, F_{});
             ++t;
         }
-        tile(t, T_{});
+        tile(t, SR{}, T_{});
+    } else if (UNR) {
+        int t = 0;
+#pragma unroll 1
+        for (; t + ARING <= nt - 1; t += ARING) {       // t is a multiple of the ring depth here: slots 0, 1, 2, 3
+            tile(t, std::integral_constant<int, 0>{}, F_{});
+            tile(t + 1, std::integral_constant<int, 1>{}, F_{});
+            tile(t + 2, std::integral_constant<int, 2>{}, F_{});
+            tile(t + 3, std::integral_constant<int, 3>{}, F_{});
+        }
+#pragma unroll 1
+        for (; t < nt - 1; ++t) tile(t, SR{}, F_{});
+        tile(nt - 1, SR{}, T_{});
     } else {
         if (nt > 1) {
-            for (int t = 0; t < nt - 1; ++t) tile(t, F_{});
+            for (int t = 0; t < nt - 1; ++t) tile(t, SR{}, F_{});
         }
-        tile(nt - 1, T_{});
+        tile(nt - 1, SR{}, T_{});
     }
     if (NS == 2) fw_mfma_drain();
 
@@ -1292,14 +1311,19 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     int var = fw_get_option(FW_OPT_ATTN_VAR);           // 0 = first kernel (generic); 64.. = two-segment ping-pong; 128.. = single stream
     // 192 = per-head-dim choice among the pre-scaled kernels (microbench, profiles/r01/attention_sp_ablation.txt): the
     // single-stream kernel for hd 128 and hd 64, the two-segment ping-pong for hd 96
-    if (var == 192) var = head_dim == 96 ? 64 : 129;
+    // round 3: hd 128 / hd 64 on the ring-unrolled form of the single-stream kernel (193): -2.4 % / -4.6 % on one box
+    // (profiles/r03/microbench_attention_unrolled.txt); hd 96 stays on the ping-pong kernel (its unrolled form spills)
+    if (var == 192) var = head_dim == 96 ? 64 : 193;
+    if ((var & 64) && var >= 128 && head_dim == 96) var &= ~64;
     if (prescaled && var >= 128) {
         // single-stream software pipeline on half tiles, pinned issue order; bit 1: one 64-row wave per SIMD (4 waves)
 #define FW_ATTN_SP(HDV, V) \
     hipLaunchKernelGGL((attention_sp_kernel<HDV, V>), dim3((unsigned)nwg), dim3(((V) & 2) ? 256 : 512), 0, st, p)
 #define FW_ATTN_SP_HD(V) \
     do { if (head_dim == 128) FW_ATTN_SP(128, V); else if (head_dim == 96) FW_ATTN_SP(96, V); else FW_ATTN_SP(64, V); } while (0)
-        if (var & 2) FW_ATTN_SP_HD(3); else FW_ATTN_SP_HD(1);
+#define FW_ATTN_SP_HD_UNR(V) do { if (head_dim == 128) FW_ATTN_SP(128, V); else FW_ATTN_SP(64, V); } while (0)
+        if (var & 64) { if (var & 2) FW_ATTN_SP_HD_UNR(67); else FW_ATTN_SP_HD_UNR(65); }       // tile loop unrolled by the ring depth
+        else if (var & 2) FW_ATTN_SP_HD(3); else FW_ATTN_SP_HD(1);
         return (int)hipGetLastError();
     }
     if (prescaled && var >= 64) {

@@ -11,6 +11,10 @@ for f in gemm.hip attention.hip elementwise.hip heads.hip fp8.hip gemm_fp8.hip a
   if [ ! -f "$o" ] || [ "${here}/$f" -nt "$o" ] || [ "${here}/fw_common.h" -nt "$o" ] || [ "${here}/../../include/fw_mi355x.h" -nt "$o" ]; then
     if [ "$f" = "fp8.hip" ]; then   # IEEE division for the fp8 quantiser: no -ffast-math
       "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "${here}/$f" -o "$o" &
+    elif [ "$f" = "attention.hip" ]; then
+      # no SLP vectorisation: hipcc otherwise packs the softmax row sums into v_pk_add_f32 (an anti-lever beside MFMAs,
+      # MI355X_MICROARCH.md) and, in the ring-unrolled kernels, spills (81 scratch accesses per four tiles at hd 128)
+      "$HIPCC" "${flags[@]}" ${FW_ATTN_EXTRA_FLAGS--fno-slp-vectorize} -c "${here}/$f" -o "$o" &
     else
       "$HIPCC" "${flags[@]}" -c "${here}/$f" -o "$o" &
     fi

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     bf16x8_t afr[2][4], bfr[2][4];
 
-    const bool tile_ts = TS != 0 && wave == 0 && lane == 0 && blockIdx.x < TILE_TS_MAX;
+    const bool tile_ts = (TS == 1 || TS == 2) && wave == 0 && lane == 0 && blockIdx.x < TILE_TS_MAX;
     if (tile_ts) {
         g_gemm_tile_ts[blockIdx.x * 6 + 0] = __builtin_amdgcn_s_memrealtime();
         g_gemm_tile_ts[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
@@ -613,9 +613,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     if (grp == 1) FW_BARRIER();
 
     int kt = 0;
-    auto slab = [&](auto first_tag, auto has1_tag, auto has2_tag) {
+    unsigned ballast = 0;     // TS == 3 only
+    auto slab = [&](auto first_tag, auto has1_tag, auto has2_tag, auto st_tag) {
         constexpr bool FIRST = decltype(first_tag)::value, HAS1 = decltype(has1_tag)::value, HAS2 = decltype(has2_tag)::value;
-        const int st = kt & 1;
+        // Round 3 experiment, measured and NOT kept: the steady loop unrolled by the two LDS stages (stage = compile-time constant,
+        // fragment-read addresses without v_add_u32) ran 9 % SLOWER (1186 vs 1293 TF/s on qkv, profiles/r03/gemm_valu_probe.txt: more
+        // address registers live, 164 B of scratch), and the VALU ballast probe (TS == 3, FW_GEMM_VAR bit 8: +16 VALU instructions per
+        // slab) costs nothing at all: VALU issue is free in this loop -- unlike in the attention kernels, whose VALU cycles add to
+        // their matrix cycles.  st_tag is always "run time" (-1).
+        constexpr int STC = decltype(st_tag)::value;
+        const int st = STC >= 0 ? STC : (kt & 1);
         const char* base = smem + st * STAGE2;
         // TIMING build: s_memtime at the start (barrier passed) and at the end of the work of every phase, slabs 16..19, work-group 0
         const bool ts_on = TS == 1 && blockIdx.x == 0 && wn == 0 && kt >= 16 && kt < 20;
@@ -646,6 +653,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[0][1], 0, 0, 0);
             if (ks == 0 && !FIRST && HAS1) FW_PP_ISSUE2(st ^ 1, kt + 1);
+            if (TS == 3 && ks == 1) {      // sensitivity probe: 16 plain VALU instructions of ballast per slab (8 here, 8 in MFMA1)
+#pragma unroll
+                for (int b8 = 0; b8 < 8; ++b8) asm volatile("v_add_u32 %0, %0, 1" : "+v"(ballast));
+            }
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[1][1], 0, 0, 0);
         }
@@ -672,6 +683,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
             acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[0][ks], acc[2][0], 0, 0, 0);
             acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0][ks], bfr[1][ks], acc[2][1], 0, 0, 0);
             if (ks == 0 && HAS2) FW_PP_ISSUE6(st, kt + 2);
+            if (TS == 3 && ks == 1) {
+#pragma unroll
+                for (int b8 = 0; b8 < 8; ++b8) asm volatile("v_add_u32 %0, %0, 1" : "+v"(ballast));
+            }
             acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[0][ks], acc[3][0], 0, 0, 0);
             acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1][ks], bfr[1][ks], acc[3][1], 0, 0, 0);
         }
@@ -685,14 +700,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
     };
     using T = std::true_type;
     using F = std::false_type;
-    slab(T{}, T{}, T{});
-    while (kt < nk - 2) slab(F{}, T{}, T{});
-    slab(F{}, T{}, F{});
-    slab(F{}, F{}, F{});
+    using SR = std::integral_constant<int, -1>;
+    slab(T{}, T{}, T{}, SR{});
+    while (kt < nk - 2) slab(F{}, T{}, T{}, SR{});
+    slab(F{}, T{}, F{}, SR{});
+    slab(F{}, F{}, F{}, SR{});
     if (grp == 0) FW_BARRIER();
+    if (TS == 3) asm volatile("" :: "v"(ballast));
     if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 2] = __builtin_amdgcn_s_memrealtime();
     epilogue_256(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
-    if (TS != 0) {
+    if (TS == 1 || TS == 2) {
         if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 3] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tile_ts) g_gemm_tile_ts[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_memrealtime();
@@ -960,8 +977,10 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
             hipLaunchKernelGGL((gemm_bf16_pp2_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+        } else if (fw_get_option(FW_OPT_GEMM_VAR) & 8) {
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<3, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // run-time-stage loop + 16 VALU of ballast per slab
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 4) {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<2, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // tile stamps only
+            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<2, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // tile stamps only (run-time-stage loop)
         } else {
             hipLaunchKernelGGL((gemm_bf16_pp2_kernel<0, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);
         }

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfw_mi355x.so")
+# FW_LIB_PATH: A/B knob for kernel experiments (two builds of the library measured on one box); never a fallback
+LIB_PATH = os.environ.get("FW_LIB_PATH") or os.path.join(_HERE, "libfw_mi355x.so")
 
 FW_DT_NONE, FW_DT_BF16, FW_DT_F32 = 0, 1, 2
 ACT = {None: 0, "none": 0, "relu": 1, "gelu_tanh": 2, "gelu_erf": 3, "silu": 4}

@@ -66,9 +66,10 @@ int fw_abi_version(void);
                                   bit 2 = tile stamps only (tools/gemm_timeline.py); value >> 4 (if non-zero) = M-tiles per group of
                                   the tile order (default 4 for outputs >= 20 column tiles wide, else 8; tools/gemm_ab.py) */
 #define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
-                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): single-stream kernel (129) for hd
-                                   128 / 64, two-segment ping-pong (64) for hd 96.  131 = single-stream with one 64-row wave per
-                                   SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
+                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): single-stream kernel with its tile
+                                   loop unrolled by the LDS ring depth (193; ring slots are compile-time, no address VALU in the
+                                   loop) for hd 128 / 64, two-segment ping-pong (64) for hd 96.  129 = single-stream, run-time
+                                   ring slots (the round-2 default); 131 / 195 = the same two with one 64-row wave per SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
                                    WITHOUT the pre-scaled flag get).  fw_attention_fp8: 8 = its in-phase kernel, anything else =
                                    its two-group ping-pong kernel */
 #define FW_OPT_COUNT       4
