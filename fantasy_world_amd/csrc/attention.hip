@@ -880,6 +880,9 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         }
 #pragma unroll
         for (int sb = 0; sb < NS; ++sb) {
+            // (round 3: moving this test out of the loop -- one test of l_run at the end bounds every half sum -- saves 3 VALU per half
+            //  on paper; in the ring-unrolled build it tipped the register allocator over the 256-VGPR edge (296 B of scratch, 126
+            //  scratch accesses per four tiles), so it stays.)
             bad |= !(ls[sb] <= 0x1p96f);
             l_run[sb] += ls[sb];
         }

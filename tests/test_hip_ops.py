@@ -178,11 +178,13 @@ def test_gemv_f32(ops, ref, parity, request):
 DEFAULT_ATTN_VAR = 192
 
 
-@pytest.fixture(params=[0, 64, 129, 131, 192], ids=["attn_v0", "attn_pp3", "attn_sp", "attn_sp_w4", "attn_default"])
+@pytest.fixture(params=[0, 64, 129, 131, 193, 195, 192],
+                ids=["attn_v0", "attn_pp3", "attn_sp", "attn_sp_w4", "attn_sp_unrolled", "attn_sp_w4_unrolled", "attn_default"])
 def attn_variant(ops, request):
     """Every attention test runs on the generic first kernel (0), on the two-segment ping-pong kernel (64), on the single-stream
-    kernel in its 8-wave (129) and 4-wave (131) forms, and on the default per-head-dim choice (192); 64+ are selected when q
-    carries the softmax scale (q_prescaled=True)."""
+    kernel in its 8-wave (129) and 4-wave (131) forms, on their ring-unrolled forms (193 / 195: compile-time LDS ring slots; hd 96
+    falls back to the rolled form) and on the default per-head-dim choice (192); 64+ are selected when q carries the softmax scale
+    (q_prescaled=True)."""
     ops.set_option("attn_var", request.param)
     yield request.param
     ops.set_option("attn_var", DEFAULT_ATTN_VAR)
