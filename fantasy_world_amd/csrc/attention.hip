@@ -1316,7 +1316,8 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     // single-stream kernel for hd 128 and hd 64, the two-segment ping-pong for hd 96
     // round 3: hd 128 / hd 64 on the ring-unrolled form of the single-stream kernel (193): -2.4 % / -4.6 % on one box
     // (profiles/r03/microbench_attention_unrolled.txt); hd 96 stays on the ping-pong kernel (its unrolled form spills)
-    if (var == 192) var = head_dim == 96 ? 64 : 193;
+    // (hd 64: the unrolled form WITHOUT the sched_group_barrier pins, 196: no scratch, 1.3 % faster than the pinned one)
+    if (var == 192) var = head_dim == 96 ? 64 : (head_dim == 64 ? 196 : 193);
     if ((var & 64) && var >= 128 && head_dim == 96) var &= ~64;
     if (prescaled && var >= 128) {
         // single-stream software pipeline on half tiles, pinned issue order; bit 1: one 64-row wave per SIMD (4 waves)
@@ -1325,7 +1326,11 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
 #define FW_ATTN_SP_HD(V) \
     do { if (head_dim == 128) FW_ATTN_SP(128, V); else if (head_dim == 96) FW_ATTN_SP(96, V); else FW_ATTN_SP(64, V); } while (0)
 #define FW_ATTN_SP_HD_UNR(V) do { if (head_dim == 128) FW_ATTN_SP(128, V); else FW_ATTN_SP(64, V); } while (0)
-        if (var & 64) { if (var & 2) FW_ATTN_SP_HD_UNR(67); else FW_ATTN_SP_HD_UNR(65); }       // tile loop unrolled by the ring depth
+        if (var & 64) {                                                                         // tile loop unrolled by the ring depth
+            if (var & 4) FW_ATTN_SP_HD_UNR(64);               // 196: without the sched_group_barrier pins
+            else if (var & 2) FW_ATTN_SP_HD_UNR(67);
+            else FW_ATTN_SP_HD_UNR(65);
+        }
         else if (var & 2) FW_ATTN_SP_HD(3); else FW_ATTN_SP_HD(1);
         return (int)hipGetLastError();
     }

@@ -110,5 +110,4 @@ def test_hot_kernels_do_not_spill():
         assert k in table, (k, sorted(table)[:5])
         assert table[k][3] == 0, f"{k}: {table[k][3]} bytes of scratch (vgpr {table[k][0]})"
         assert table[k][0] <= 256 and table[k][2] <= 160 * 1024
-    # the hd-64 unrolled kernel keeps 5 dwords in scratch outside its steady loop and is still 4.6 % faster than the rolled form
-    assert table["attention_sp_kernel<64, 65>"][3] <= 32
+    assert table["attention_sp_kernel<64, 64>"][3] == 0          # the hd-64 default (ring-unrolled, unpinned)
