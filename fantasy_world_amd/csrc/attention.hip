@@ -460,13 +460,18 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
     if (grp == 1) FW_ABARRIER();
 
     int t = 0;
-    auto tile = [&](auto has1_tag) {
+    // slot_tag: ring slot of tile t when it is known at compile time (the steady loop is unrolled by the ring depth, round 3: the
+    // fragment-read addresses then fold into ds_read immediates), -1 = t & (ARING - 1)
+    auto tile = [&](auto slot_tag, auto has1_tag) {
+        constexpr int SL = decltype(slot_tag)::value;
         constexpr bool has1 = decltype(has1_tag)::value;
+        const int s_cur = SL >= 0 ? SL : (t & (ARING - 1));
+        const int s_nxt = SL >= 0 ? ((SL + 1) & (ARING - 1)) : ((t + 1) & (ARING - 1));
         const bool steady = t + 4 < nt;
         // ------------------------------------------------------------ V(t): Vt fragments -> registers, softmax
         FW_TS(0);
         {
-            const char* vb = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+            const char* vb = smem + s_cur * VT_TILE_BYTES;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)       // first half of the Vt fragments; the rest is fetched behind the first PV MFMAs
 #pragma unroll
@@ -536,8 +541,8 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
             if (t + 4 < nt) issue_k(t + 4);
             if (t + 3 < nt) issue_v(t + 3);
         }
-        const char* kb = smem + ((t + 1) & (ARING - 1)) * K_TILE_BYTES;
-        const char* vb2 = smem + (t & (ARING - 1)) * VT_TILE_BYTES;
+        const char* kb = smem + s_nxt * K_TILE_BYTES;
+        const char* vb2 = smem + s_cur * VT_TILE_BYTES;
         constexpr int HF = NFR / 2;
         // fragment register block fr[0..NFR): every MFMA is followed by the ds_read that refills a register it (or an earlier
         // MFMA) released, >= HF MFMAs ahead of its consumer:
@@ -602,8 +607,14 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         FW_ABARRIER();
         FW_TS(6);
     };
-    for (; t < nt - 1; ++t) tile(std::true_type{});
-    tile(std::false_type{});
+    // (round 3: unrolling THIS loop by the ring depth -- slot_tag 0..3, as in attention_sp_kernel -- measured 5 % SLOWER at hd 96
+    //  (4.54-4.60 ms against 4.34-4.37 ms on one box): the two wave groups already run different phases of the loop, and the four
+    //  copies cost more than the 7 address instructions per tile they save.  slot_tag stays run time.)
+    {
+        using SRT = std::integral_constant<int, -1>;
+        for (; t < nt - 1; ++t) tile(SRT{}, std::true_type{});
+        tile(SRT{}, std::false_type{});
+    }
     if (grp == 0) FW_ABARRIER();
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
