@@ -138,7 +138,8 @@ class CfgPairing:
         return forward(context, return_prediction)
 
 
-def install(model, ops=None, device=None, cache_step_invariants=True, precision="bf16", topo=None, shard=None):
+def install(model, ops=None, device=None, cache_step_invariants=True, precision="bf16", topo=None, shard=None,
+            release_reference_weights=False):
     """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
     tests may inject another op set to exercise this boundary on CPU.  `cache_step_invariants`: keep the context embeddings,
     the per-block cross-attention K/V and the camera adapter's Pluecker term across the calls of a generation (the caller
@@ -150,6 +151,11 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     sequence-sharded over the ranks of this process's group (head all-to-all, parallel.py) and, with two CFG groups, the two
     forwards of a sampling step run concurrently under the unchanged reference loop (CfgPairing).  Every rank returns the full
     noise prediction (and, on the last step, the full prediction dict), identical across ranks.
+
+    `release_reference_weights=True`: after packing (geometry heads and pose encoder included, eagerly) the storage of every
+    parameter that was packed is released on the reference module tree (the Parameters stay, with empty data): the model then holds
+    ONE copy of its weights -- the packed one -- instead of 28 GB + 36 GB per expert.  One-way: `uninstall()` cannot bring the
+    reference forward back (it raises), load the checkpoint again for that.
 
     The weights are SNAPSHOT at install time into packed copies (36 GB for the 14B model, next to the reference's own): call
     install() after checkpoint loading / LoRA merging / .to(dtype).  A later change of the live parameters is detected at the
@@ -174,6 +180,20 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     else:
         engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
                               cache_step_invariants=cache_step_invariants, precision=precision, shard=shard)
+    released = []
+    if release_reference_weights:
+        if engine.heads_cfg is not None:
+            engine.geometry_heads()                              # pack now: their source tensors are about to go
+        keep = ("camera_condition.pose_encoder.",)                # packed lazily by get_pose_fea
+        if engine.heads_cfg is None:                             # a head is disabled: the reference's own head modules stay in use
+            keep += ("vggt.camera_head.", "vggt.depth_head.", "vggt.point_head.", "vggt.track_head.")
+        packed_prefixes = ("pipe.dit.", "IRGBlock.", "vggt.")
+        with torch.no_grad():
+            for name, p in params.items():
+                if name.startswith(packed_prefixes) and not name.startswith(keep):
+                    p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+                    released.append(name)
+        model._fw_released_weights = len(released)
     watch = _WeightWatch(model)
     engine.weight_watch = watch
     del params
@@ -264,6 +284,9 @@ def install_vae(vae, ops=None, device=None):
 
 
 def uninstall(model):
+    if getattr(model, "_fw_released_weights", 0):
+        raise RuntimeError("install(..., release_reference_weights=True) released the reference's own copy of the weights: the "
+                           "reference forward cannot be restored -- build / load the model again")
     if hasattr(model, "_fw_reference_joint_forward"):
         model.joint_forward = model._fw_reference_joint_forward
         del model._fw_reference_joint_forward

@@ -45,6 +45,34 @@ def test_install_rebinds_joint_forward_on_reference_model(case_l2):
     assert not hasattr(model, "_fw_engine") and again.shape == want.shape
 
 
+def test_install_can_release_the_reference_copy_of_the_weights(case_pred):
+    """install(release_reference_weights=True): one resident copy of the weights (the packed one) instead of two -- the packed
+    parameters' storage is released on the reference tree, joint_forward (incl. the geometry heads, packed eagerly) is unchanged,
+    and uninstall() refuses, because the reference forward is gone."""
+    from conftest import PRED_KEYS
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install, uninstall
+    c, ins = case_pred, case_pred.inputs
+    model = ref_harness.build_reference_wan21(c.cfg, weights=c.weights, heads_cfg=c.hc)
+    before = sum(p.numel() for p in model.parameters())
+    eng = install(model, ops=TorchRefOps(), release_reference_weights=True)
+    after = sum(p.numel() for p in model.parameters())
+    assert model._fw_released_weights > 100 and after < 0.05 * before, (before, after)
+    assert model.pipe.dit.blocks[0].ffn[0].weight.numel() == 0 and model.IRGBlock[0].x_dit.ffn[0].weight.numel() == 0
+    kw = dict(timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
+              use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+              plucker_context_lens=ins["plucker_context_lens"], return_prediction=True)
+    got, pred = model.joint_forward(ins["x"], **kw)
+    assert rel_l2(got, c.golden["noise_pred"]) < 2e-5
+    for k in PRED_KEYS:
+        assert rel_l2(pred[k], c.golden[k]) < 5e-5, k
+    got2, _ = model.joint_forward(ins["x"], **kw)                 # the weight watch accepts the released tree
+    assert torch.equal(got2, got)
+    with pytest.raises(RuntimeError, match="released"):
+        uninstall(model)
+
+
 def test_install_on_reference_wan22_model(case_w22):
     """Same boundary on the Wan2.2 flavour: the M22 signature (control_camera_latents_input, no clip_feature / plucker_fea,
     FantasyWorld/fusion/model_wan22.py:231-242) is kept; the engine reads the control adapter off pipe.dit."""
