@@ -113,14 +113,17 @@ class CfgPairing:
     path and re-learns.  Every rank runs the same script on the same inputs, so every rank takes the same branch and returns
     the same tensors as a single-GPU run."""
 
-    def __init__(self, topo):
+    def __init__(self, topo=None):
+        # topo = None: ONE GPU -- the pair is computed as one merged pass over 2L rows (FusionEngine.joint_forward_pair: weights read
+        # once, bit-identical to two calls) at the loop's first call, the second call is answered from the stash all the same
         self.topo = topo
         self.pair = None          # (first context, second context) of a step, learned
         self.last = None          # (x, timestep, context) of the previous plain call
         self.stash = None         # (x, timestep, second-context result) waiting for the second call
 
-    def run(self, forward, x, timestep, context, uncond, return_prediction):
-        """forward(context, want_prediction) -> (out, prediction) on this rank's sequence-shard group."""
+    def run(self, forward, x, timestep, context, uncond, return_prediction, forward_pair=None):
+        """forward(context, want_prediction) -> (out, prediction) on this rank's sequence-shard group;
+        forward_pair(ctx_first, ctx_second) -> (out_first, out_second): the merged pass (single GPU only)."""
         plain = uncond or return_prediction
         st = self.stash
         if st is not None and not plain and st[0] is x and st[1] is timestep and self.pair is not None and context is self.pair[1]:
@@ -128,8 +131,11 @@ class CfgPairing:
             return st[2], None
         self.stash = None
         if not plain and self.pair is not None and context is self.pair[0]:
-            out, _ = forward(self.pair[self.topo.cfg_rank], False)
-            first, second = self.topo.gather_cfg(out)
+            if self.topo is not None:
+                out, _ = forward(self.pair[self.topo.cfg_rank], False)
+                first, second = self.topo.gather_cfg(out)
+            else:
+                first, second = forward_pair(self.pair[0], self.pair[1])
             self.stash = (x, timestep, second)
             return first, None
         if self.last is not None and self.last[0] is x and self.last[1] is timestep and self.last[2] is not context:
@@ -139,7 +145,7 @@ class CfgPairing:
 
 
 def install(model, ops=None, device=None, cache_step_invariants=True, precision="bf16", topo=None, shard=None,
-            release_reference_weights=False):
+            release_reference_weights=False, merge_cfg=True):
     """Replace `model.joint_forward` by the MI355X engine.  `ops` defaults to HipOps (raises without a GPU / library);
     tests may inject another op set to exercise this boundary on CPU.  `cache_step_invariants`: keep the context embeddings,
     the per-block cross-attention K/V and the camera adapter's Pluecker term across the calls of a generation (the caller
@@ -151,6 +157,10 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     sequence-sharded over the ranks of this process's group (head all-to-all, parallel.py) and, with two CFG groups, the two
     forwards of a sampling step run concurrently under the unchanged reference loop (CfgPairing).  Every rank returns the full
     noise prediction (and, on the last step, the full prediction dict), identical across ranks.
+
+    `merge_cfg` (single GPU, default on): the two forwards of a sampling step -- two sequential joint_forward calls of the unchanged
+    reference loop that differ only in the text context -- run as ONE pass over 2L rows from the second step on (CfgPairing with
+    FusionEngine.joint_forward_pair): bit-identical outputs, +1.2 % steps/s (profiles/r03/bench_r3_merge_cfg.log).
 
     `release_reference_weights=True`: after packing (geometry heads and pose encoder included, eagerly) the storage of every
     parameter that was packed is released on the reference module tree (the Parameters stay, with empty data): the model then holds
@@ -172,6 +182,8 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
         assert shard is None or shard is topo.shard, "pass either topo or shard"
         shard = topo.shard
     pairing = CfgPairing(topo) if topo is not None and topo.cfg_groups == 2 else None
+    if pairing is None and merge_cfg and shard is None and (topo is None or topo.world == 1):
+        pairing = CfgPairing(None)
     params = dict(model.named_parameters())
     if topo is not None and topo.tp is not None:          # north_star's head / FFN-column partition (tensor_parallel.py)
         from .tensor_parallel import TPFusionEngine
@@ -209,8 +221,13 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                                         plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
                                         uncond=uncond, return_prediction=want_prediction, camera_token=camera_token,
                                         control_camera_latents_input=control_camera_latents_input)
+        def forward_pair(ctx_a, ctx_b):
+            a, b, _ = engine.joint_forward_pair(x, timestep, ctx_a, ctx_b, clip_feature=clip_feature, y=y, plucker_fea=plucker_fea,
+                                                plucker_context_lens=plucker_context_lens, uncond=uncond, camera_token=camera_token,
+                                                control_camera_latents_input=control_camera_latents_input)
+            return a, b
         if pairing is not None:
-            out, outputs = pairing.run(forward, x, timestep, context, uncond, return_prediction)
+            out, outputs = pairing.run(forward, x, timestep, context, uncond, return_prediction, forward_pair)
         else:
             out, outputs = forward(context, return_prediction)
         if not return_prediction:

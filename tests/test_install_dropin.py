@@ -73,6 +73,43 @@ def test_install_can_release_the_reference_copy_of_the_weights(case_pred):
         uninstall(model)
 
 
+def test_install_merges_the_cfg_pair_under_the_reference_loop(case_l2):
+    """Single GPU, install() default (merge_cfg=True): the reference loop's two sequential joint_forward calls per step
+    (model_wan21.py:295-319) become ONE merged pass from the second step on -- learnt from the identity of the latents / timestep /
+    context objects, answered from a stash -- with the latents of the plain loop."""
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install
+    from fantasy_world_amd.sampler import FlowMatchScheduler
+    case, ins = case_l2, case_l2.inputs
+    model = ref_harness.build_reference_wan21(case.cfg, weights=case.weights)
+    sched = FlowMatchScheduler()
+    sched.set_timesteps(4)
+    cond = dict(clip_feature=ins["clip_feature"], y=ins["y"], use_gradient_checkpointing=False, camera_token=None,
+                plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"])
+
+    def loop():
+        lat = ins["x"]
+        for step in range(3):
+            t = sched.timesteps[step].reshape(1)
+            with torch.no_grad():
+                pos, _ = model.joint_forward(lat, timestep=t, context=ins["context"], **cond)
+                neg, _ = model.joint_forward(lat, timestep=t, context=ins["context_neg"], **cond)
+            lat = sched.step(neg + 5.0 * (pos - neg), step, lat)
+        return lat
+    want = loop()
+    eng = install(model, ops=TorchRefOps())
+    passes = []
+    orig = eng._forward
+    eng._forward = lambda x, t, contexts, *a, **k: (passes.append(len(contexts)), orig(x, t, contexts, *a, **k))[1]
+    got = loop()
+    assert passes == [1, 1, 2, 2], passes          # step 0: two plain forwards (learning); steps 1, 2: one merged pass each
+    assert eng.cfg_pairing is not None and eng.cfg_pairing.pair[0] is ins["context"] and eng.cfg_pairing.pair[1] is ins["context_neg"]
+    assert rel_l2(got, want) < 2e-5
+    eng2 = install(model, ops=TorchRefOps(), merge_cfg=False)
+    assert eng2.cfg_pairing is None
+
+
 def test_install_on_reference_wan22_model(case_w22):
     """Same boundary on the Wan2.2 flavour: the M22 signature (control_camera_latents_input, no clip_feature / plucker_fea,
     FantasyWorld/fusion/model_wan22.py:231-242) is kept; the engine reads the control adapter off pipe.dit."""

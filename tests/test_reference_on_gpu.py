@@ -41,7 +41,7 @@ def _cast(kw, dtype):
 
 def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
     """The reference's own sampling loop (scheduler, CFG combine, `latents.to('cuda')`, return_prediction on the last step)
-    around the rebound joint_forward + get_pose_fea, 2 steps, against the reference itself on PyTorch-ROCm fp32; the reference's
+    around the rebound joint_forward + get_pose_fea, 3 steps, against the reference itself on PyTorch-ROCm fp32; the reference's
     bf16-autocast configuration (what inference_wan21.py runs) is measured beside it as the yardstick."""
     from oracle import ref_harness
     from fantasy_world_amd import install, uninstall, synth
@@ -51,7 +51,7 @@ def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
     W.update(synth.make_pose_encoder_weights())
     model = _to_dev(ref_harness.build_reference_wan21(c.cfg, weights=W, heads_cfg=c.hc), torch.float32)
     assert not model._fw_unused
-    kw = _gen_kwargs(c, steps=2)
+    kw = _gen_kwargs(c, steps=3)            # step 1 learns the CFG pair, step 2 runs the merged pass, step 3 (last) returns the prediction
     want, wpred = model.generate_video(**kw)                               # the reference, fp32, PyTorch-ROCm kernels
     torch.cuda.synchronize()
 
