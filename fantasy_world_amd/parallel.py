@@ -15,8 +15,9 @@ Two levels, chosen from what the path offers and what the xGMI mesh (7 point-to-
        as n column blocks of H/n heads and come back as [L, 3*(H/n)*hd]; attention runs over the FULL sequence for H/n heads;
        the output returns by the inverse all-to-all.  Per DiT block each GPU sends (n-1)/n of 126 MB + 42 MB instead of
        receiving (n-1)/n of the 671 MB k|v all-gather (4x fewer bytes), and still nothing is reduced in low precision.
-     * bicross attention (12 heads, not divisible by 8) and any head count that does not divide: all-gather of the rotated
-       rows (q|v1: 151 MB, k|v2: 151 MB per IRG block).
+     * bicross attention (12 heads): head exchange as well when the group size divides 12 (2, 3, 4, 6 ranks: the 2 x 4 layout of 8
+       GPUs; round 3) -- q|v1 and k|v2 out, both directions over the full sequences for 12/n heads, o1 / o2 back; otherwise, and for
+       any head count that does not divide: all-gather of the rotated rows (q|v1: 151 MB, k|v2: 151 MB per IRG block).
    Head/FFN-column tensor parallelism (the NVSwitch habit) would instead all-reduce the full [L,5120] activation three times
    per DiT block (1.76 GB received per GPU per block, partial sums rounded to bf16, cross-GPU statistics for the full-width
    q/k RMSNorm) -- see DESIGN.md section 6 for the byte table.

@@ -49,7 +49,7 @@ def _load_weights(path):
     return torch.load(path, map_location="cpu", mmap=True, weights_only=True)
 
 
-def _worker(rank, world, port, grid, outdir, wpath):
+def _worker(rank, world, port, grid, outdir, wpath, bicross_gather=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -63,16 +63,20 @@ def _worker(rank, world, port, grid, outdir, wpath):
     W = _load_weights(wpath)
     ins = synth.make_inputs(cfg, *grid, seed=3)
     eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(), shard=SequenceShard(rank, world), heads_cfg=_hc())
+    eng.bicross_head_exchange = not bicross_gather
+    from fantasy_world_amd import parallel
+    stats = parallel.enable_comm_stats()
     out, pred = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
                                   plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"],
                                   return_prediction=True)
-    torch.save((out, pred), os.path.join(outdir, f"out_{rank}.pt"))
+    n_a2a = sum(1 for r in stats.records if r[0] == "all_to_all_qkv")
+    torch.save((out, pred, n_a2a), os.path.join(outdir, f"out_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,grid", [(3, (4, 4, 12)), (4, (5, 4, 12))])
-def test_sequence_shard_matches_single_process(world, grid, tmp_path, shared_weights):
+@pytest.mark.parametrize("world,grid,bicross_gather", [(3, (4, 4, 12), False), (4, (5, 4, 12), False), (4, (5, 4, 12), True)])
+def test_sequence_shard_matches_single_process(world, grid, bicross_gather, tmp_path, shared_weights):
     """world 3: 40 and 16 heads do not divide -> K/V all-gather fallback, uneven frame split (2,1,1).  world 4 (the shard of an
     8-GPU run): 10 DiT heads per rank exchanged in the groups (4, 6), 4 VGGT heads, 3 bicross heads, frames split (2,1,1,1) so the
     all-to-all row splits are uneven.  (World 2 inside a CFG group: test_cfg_parallel_denoise_step_matches_single_process.)  Run as the LAST
@@ -88,10 +92,14 @@ def test_sequence_shard_matches_single_process(world, grid, tmp_path, shared_wei
                                     plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"],
                                     return_prediction=True)
     del eng
-    mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path), wpath), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path), wpath, bicross_gather), nprocs=world, join=True)
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
     for r in range(world):
-        got, pred = torch.load(os.path.join(str(tmp_path), f"out_{r}.pt"))
+        got, pred, n_a2a = torch.load(os.path.join(str(tmp_path), f"out_{r}.pt"))
+        # bicross (12 heads: 3 and 4 ranks divide them): head exchange = two more q|k|v-type all-to-alls per IRG block (round 3), or
+        # the row all-gathers when switched off.  World 4 also exchanges the DiT (2 blocks x 2 head groups) and VGGT-global heads.
+        base = 0 if world == 3 else 2 * 2 + 1
+        assert n_a2a == base + (0 if bicross_gather else 2), (world, bicross_gather, n_a2a)
         assert rel(got, want) < 1e-5, (r, rel(got, want))
         # last step: the frame-sharded output_list is gathered and every rank computes the same prediction dict
         for k, v in wpred.items():
