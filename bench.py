@@ -297,7 +297,7 @@ def main():
         for rnd in ("r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
-                    traffic = float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])
+                    traffic = nb * float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])    # merged CFG: batch 2 per launch
                 break
             except (OSError, KeyError, ValueError):
                 continue
