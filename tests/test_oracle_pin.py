@@ -156,3 +156,26 @@ def test_vae_decoder_host_logic_matches_reference_golden(vae_case):
     assert rel_l2(tiny, got) < 1e-5
     emu = VaeDecoder(c.weights.__getitem__, ref_ops.TorchRefOps(emulate_bf16=True)).decode(c.latents)
     assert rel_l2(emu, want) < 2e-2              # the yardstick behind the GPU tolerance
+
+
+def test_staged_reference_bundle_is_the_unmodified_reference():
+    """oracle/_ref/reference_py.tgz (what the GPU box runs as the checker, oracle/stage_ref.sh) holds the reference's Python files
+    BYTE FOR BYTE: every member is compared with /root/reference.  Runs only where both exist (the build container)."""
+    import hashlib
+    import os
+    import tarfile
+    from oracle import ref_locate
+    root = "/root/reference"
+    if not (os.path.isfile(ref_locate.BUNDLE) and os.path.isdir(os.path.join(root, "FantasyWorld"))):
+        pytest.skip("needs both the staged bundle and /root/reference")
+    n = 0
+    with tarfile.open(ref_locate.BUNDLE, "r:gz") as tar:
+        for m in tar.getmembers():
+            if not m.isfile():
+                continue
+            with open(os.path.join(root, m.name), "rb") as f:
+                want = hashlib.sha256(f.read()).hexdigest()
+            got = hashlib.sha256(tar.extractfile(m).read()).hexdigest()
+            assert got == want, m.name
+            n += 1
+    assert n > 200, n          # FantasyWorld/ + the two inference scripts
