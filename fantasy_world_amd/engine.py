@@ -15,6 +15,7 @@ Numerics: residual streams (DiT x, VGGT tokens) are kept in fp32 (the reference 
 the VGGT stream in fp32 after the first modulated block); matmul inputs are bf16, accumulation fp32; all
 normalisation statistics, softmax and rotary math are fp32 (tables from fp64).
 """
+import types
 from typing import Callable
 
 import torch
@@ -561,60 +562,12 @@ class FusionEngine:
 
     def _forward(self, x, timestep, contexts, clip_feature, y, plucker_fea, plucker_context_lens, uncond, return_prediction,
                  camera_token, control_camera_latents_input, collect):
-        cfg, ops, sh = self.cfg, self.ops, self.shard
-        nb = self._nb = len(contexts)                          # samples stacked along the token rows (batch-major)
-        assert x.shape[0] == 1, "the reference samples with batch 1 (model_wan21.py:254-258)"
-        F, H2, W2 = x.shape[2:]
-        h, w = H2 // 2, W2 // 2
-        hw = h * w
-        L = F * hw
-        P = cfg.n_special + hw
-        tabs = self._get_tables(F, h, w)
-        if sh is not None:
-            tabs = sh.localize_tables(tabs, F, hw, cfg.n_special)
+        cfg, sh = self.cfg, self.shard
+        st = self._prologue(x, timestep, contexts, clip_feature, y, plucker_fea, control_camera_latents_input)
+        nb, P, tabs, xs, t_mod, e0 = st.nb, st.P, st.tabs, st.xs, st.t_mod, st.e0
+        ctx_txt, ctx_img, plucker = st.ctx_txt, st.ctx_img, st.plucker
         # tests: collect["per_block"] = fn(kind, index, stream) is called with the fp32 streams after every block
         per_block = None if collect is None else collect.get("per_block")
-
-        # ---- A1: time embeddings, fp32 (wan_video_dit.py:393-399, vggt.py:126-130) ----------------------------
-        sin = ops.sinusoid(timestep, cfg.freq_dim)
-        t = ops.linear_f32(ops.linear_f32(sin, self.time0, act="silu"), self.time2)           # [D]
-        t_mod = ops.linear_f32(t, self.timep, silu_in=True).view(6, cfg.dim)
-        ev = ops.linear_f32(ops.linear_f32(sin, self.vtime0, act="silu"), self.vtime2)
-        e0 = ops.linear_f32(ev, self.vtimep, silu_in=True).view(6, cfg.vggt_dim)
-
-        # ---- A2: context embeddings (wan_video_dit.py:388-392, 324-341) ----------------------------------------
-        embs = [self.invariants.get("ctx_txt", (c,), lambda c=c: ops.linear(
-            ops.linear(ops.to_act(c[0]), self.text0, act="gelu_tanh"), self.text2)) for c in contexts]
-        ctx_txt = embs[0] if nb == 1 else torch.cat(embs, dim=0)                               # [nb * 512, D]
-        self._ctx_sources, self._img_sources = tuple(contexts), (clip_feature,)
-        ctx_img = None
-        if cfg.has_image_input:
-            def image_ctx():
-                ci = ops.layernorm(ops.to_act(clip_feature[0]), w=self.img_ln0[0], b=self.img_ln0[1], eps=1e-5)
-                ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
-                return ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
-            ctx_img = self.invariants.get("ctx_img", (clip_feature,), image_ctx)
-            if nb > 1:
-                ctx_img = ctx_img.repeat(nb, 1)
-
-        # ---- A3: patchify (Conv3d k=s=(1,2,2) as GEMM) ---------------------------------------------------------
-        # Wan2.1 concatenates y when the DiT has image input (model_wan21.py:125-126), Wan2.2 whenever y is given (model_wan22.py:252-253)
-        use_y = y is not None and (cfg.has_image_input or cfg.control_adapter)
-        patches = ops.patchify(x, y if use_y else None, self.kpatch)                           # [L, 192] (x | y channels)
-        ycam = None
-        if cfg.control_adapter and control_camera_latents_input is not None:
-            ycam = self._control_features(control_camera_latents_input, F, h, w)               # fp32 [L, D]
-        plucker = None
-        if plucker_fea is not None and cfg.camera_adapter:
-            if not self._plucker_all_zero(plucker_fea):                                        # camera_control.py:111
-                plucker = self.invariants.get("plucker_rows", (plucker_fea,), lambda: (
-                    ops.to_act(plucker_fea[0]) if sh is None else sh.take_dit_rows(ops.to_act(plucker_fea[0]))))
-        if sh is not None:
-            patches = sh.take_dit_rows(patches)
-            ycam = None if ycam is None else sh.take_dit_rows(ycam)
-        xs = ops.linear(patches, self.patch, res=ycam, out_f32=True)                          # fp32 residual stream
-        if nb > 1:
-            xs = xs.repeat(nb, 1)             # the merged samples start from the same embedded latents; they diverge at the first cross-attention
 
         # ---- PCB: DiT blocks [0, start_index) ------------------------------------------------------------------
         for b in range(cfg.start_index):
@@ -626,36 +579,11 @@ class FusionEngine:
         if collect is not None:
             collect["x_after_pcb"] = xs.clone()
 
-        # ---- bridge: DiT tokens -> VGGT tokens (model_wan21.py:170-175) -----------------------------------------
-        ptok = ops.linear(ops.cast_act(xs), self.proj)                                         # [L(local), C]
-        if sh is not None:
-            ptok = sh.dit_rows_to_frames(ptok, hw)                                             # this rank's frames
-            S_loc = sh.my_frames
-        else:
-            S_loc = F
-        if nb == 1:
-            tok = ops.assemble_tokens(ptok, self._special_for(sh), S_loc, hw)                  # fp32 [S_loc*P, C]
-        else:                                 # frame 0 of EVERY sample takes the first-frame camera / register tokens
-            Ln = ptok.shape[0] // nb
-            tok = torch.cat([ops.assemble_tokens(ptok[i * Ln:(i + 1) * Ln], self.special, S_loc, hw) for i in range(nb)], dim=0)
-        if camera_token is not None:
-            # CamTokenProjector (vggt/layers/block.py:276-297, aggregator.py:265-266): the learned camera token of every frame is
-            # replaced by an MLP of 4 consecutive pose encodings (the sequence is padded with 3 copies of its first pose)
-            ct = ops.to_act(camera_token[0])                                                   # [V, 9]
-            ct = torch.cat([ct, ct[:1].expand(3, -1)], dim=0).reshape(-1, 36)                   # [S, 36]
-            assert ct.shape[0] == F, (camera_token.shape, F)
-            ct = _pad_to(ct, 1, 64)
-            cam = ops.linear(ops.linear(ct, self.camtok0, act="gelu_erf"), self.camtok2, out_f32=True)     # fp32 [S, C]
-            if sh is not None:
-                cam = cam[sh.first_frame:sh.first_frame + S_loc]
-            tok.view(nb * S_loc, P, cfg.vggt_dim)[:, 0, :] = cam if nb == 1 else cam.repeat(nb, 1)
+        tok, S_loc = self._entry_tokens(st, camera_token)
         if collect is not None:
             collect["tokens_in"] = tok.clone()
 
-        need = set()
-        if return_prediction:
-            # the layers the geometry heads read: dpt_head.py:44 (23, 17, 11, 7) and camera_head.py:89 (the last one)
-            need = set(self.heads_cfg.layer_idx if self.heads_cfg is not None else (7, 11, 17, 23)) | {cfg.n_irg - 1}
+        need = self._layers_for_heads(return_prediction)
         outputs = {}
         for i in range(cfg.n_irg):
             fb = self.frame[i]
@@ -685,13 +613,112 @@ class FusionEngine:
         if collect is not None:
             collect["x_final"] = xs.clone()
             collect["tokens_final"] = tok.clone()
+        return self._epilogue(st, x.dtype, outputs, return_prediction)
 
-        # ---- head (wan_video_dit.py:344-358) + unpatchify -------------------------------------------------------
-        xn = ops.layernorm(xs, scale=self.head_mod[1] + t, shift=self.head_mod[0] + t, eps=cfg.eps)
+    # The three parts of a forward that do not depend on how the blocks are partitioned (the tensor-parallel engine,
+    # tensor_parallel.py, runs the same three around its own block loop).
+    def _prologue(self, x, timestep, contexts, clip_feature, y, plucker_fea, control_camera_latents_input):
+        """Time / text / image embeddings and the patchified latents: everything ahead of the first block.  Returns the forward's
+        state: dims (F, h, w, hw, L, P, nb), tables, t / t_mod / e0, ctx_txt / ctx_img, plucker rows, and the fp32 stream xs."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        st = types.SimpleNamespace()
+        nb = st.nb = self._nb = len(contexts)                  # samples stacked along the token rows (batch-major)
+        assert x.shape[0] == 1, "the reference samples with batch 1 (model_wan21.py:254-258)"
+        F, H2, W2 = x.shape[2:]
+        h, w = H2 // 2, W2 // 2
+        hw = h * w
+        st.F, st.h, st.w, st.hw, st.L, st.P = F, h, w, hw, F * hw, cfg.n_special + hw
+        tabs = self._get_tables(F, h, w)
+        if sh is not None:
+            tabs = sh.localize_tables(tabs, F, hw, cfg.n_special)
+        st.tabs = tabs
+
+        # ---- A1: time embeddings, fp32 (wan_video_dit.py:393-399, vggt.py:126-130) ----------------------------
+        sin = ops.sinusoid(timestep, cfg.freq_dim)
+        st.t = ops.linear_f32(ops.linear_f32(sin, self.time0, act="silu"), self.time2)        # [D]
+        st.t_mod = ops.linear_f32(st.t, self.timep, silu_in=True).view(6, cfg.dim)
+        ev = ops.linear_f32(ops.linear_f32(sin, self.vtime0, act="silu"), self.vtime2)
+        st.e0 = ops.linear_f32(ev, self.vtimep, silu_in=True).view(6, cfg.vggt_dim)
+
+        # ---- A2: context embeddings (wan_video_dit.py:388-392, 324-341) ----------------------------------------
+        embs = [self.invariants.get("ctx_txt", (c,), lambda c=c: ops.linear(
+            ops.linear(ops.to_act(c[0]), self.text0, act="gelu_tanh"), self.text2)) for c in contexts]
+        st.ctx_txt = embs[0] if nb == 1 else torch.cat(embs, dim=0)                            # [nb * 512, D]
+        self._ctx_sources, self._img_sources = tuple(contexts), (clip_feature,)
+        st.ctx_img = None
+        if cfg.has_image_input:
+            def image_ctx():
+                ci = ops.layernorm(ops.to_act(clip_feature[0]), w=self.img_ln0[0], b=self.img_ln0[1], eps=1e-5)
+                ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
+                return ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
+            st.ctx_img = self.invariants.get("ctx_img", (clip_feature,), image_ctx)
+            if nb > 1:
+                st.ctx_img = st.ctx_img.repeat(nb, 1)
+
+        # ---- A3: patchify (Conv3d k=s=(1,2,2) as GEMM) ---------------------------------------------------------
+        # Wan2.1 concatenates y when the DiT has image input (model_wan21.py:125-126), Wan2.2 whenever y is given (model_wan22.py:252-253)
+        use_y = y is not None and (cfg.has_image_input or cfg.control_adapter)
+        patches = ops.patchify(x, y if use_y else None, self.kpatch)                           # [L, 192] (x | y channels)
+        ycam = None
+        if cfg.control_adapter and control_camera_latents_input is not None:
+            ycam = self._control_features(control_camera_latents_input, F, h, w)               # fp32 [L, D]
+        st.plucker = None
+        if plucker_fea is not None and cfg.camera_adapter:
+            if not self._plucker_all_zero(plucker_fea):                                        # camera_control.py:111
+                st.plucker = self.invariants.get("plucker_rows", (plucker_fea,), lambda: (
+                    ops.to_act(plucker_fea[0]) if sh is None else sh.take_dit_rows(ops.to_act(plucker_fea[0]))))
+        if sh is not None:
+            patches = sh.take_dit_rows(patches)
+            ycam = None if ycam is None else sh.take_dit_rows(ycam)
+        xs = ops.linear(patches, self.patch, res=ycam, out_f32=True)                          # fp32 residual stream
+        if nb > 1:
+            xs = xs.repeat(nb, 1)             # the merged samples start from the same embedded latents; they diverge at the first cross-attention
+        st.xs = xs
+        return st
+
+    def _entry_tokens(self, st, camera_token):
+        """The bridge DiT tokens -> VGGT tokens (model_wan21.py:170-175): returns (fp32 token stream [nb * S_loc * P, C], S_loc)."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        nb, F, hw, P = st.nb, st.F, st.hw, st.P
+        ptok = ops.linear(ops.cast_act(st.xs), self.proj)                                      # [L(local), C]
+        if sh is not None:
+            ptok = sh.dit_rows_to_frames(ptok, hw)                                             # this rank's frames
+            S_loc = sh.my_frames
+        else:
+            S_loc = F
+        if nb == 1:
+            tok = ops.assemble_tokens(ptok, self._special_for(sh), S_loc, hw)                  # fp32 [S_loc*P, C]
+        else:                                 # frame 0 of EVERY sample takes the first-frame camera / register tokens
+            Ln = ptok.shape[0] // nb
+            tok = torch.cat([ops.assemble_tokens(ptok[i * Ln:(i + 1) * Ln], self.special, S_loc, hw) for i in range(nb)], dim=0)
+        if camera_token is not None:
+            # CamTokenProjector (vggt/layers/block.py:276-297, aggregator.py:265-266): the learned camera token of every frame is
+            # replaced by an MLP of 4 consecutive pose encodings (the sequence is padded with 3 copies of its first pose)
+            ct = ops.to_act(camera_token[0])                                                   # [V, 9]
+            ct = torch.cat([ct, ct[:1].expand(3, -1)], dim=0).reshape(-1, 36)                   # [S, 36]
+            assert ct.shape[0] == F, (camera_token.shape, F)
+            ct = _pad_to(ct, 1, 64)
+            cam = ops.linear(ops.linear(ct, self.camtok0, act="gelu_erf"), self.camtok2, out_f32=True)     # fp32 [S, C]
+            if sh is not None:
+                cam = cam[sh.first_frame:sh.first_frame + S_loc]
+            tok.view(nb * S_loc, P, cfg.vggt_dim)[:, 0, :] = cam if nb == 1 else cam.repeat(nb, 1)
+        return tok, S_loc
+
+    def _layers_for_heads(self, return_prediction):
+        """The aggregator layers the geometry heads read: dpt_head.py:44 (23, 17, 11, 7) and camera_head.py:89 (the last one)."""
+        if not return_prediction:
+            return set()
+        return set(self.heads_cfg.layer_idx if self.heads_cfg is not None else (7, 11, 17, 23)) | {self.cfg.n_irg - 1}
+
+    def _epilogue(self, st, out_dtype, outputs, return_prediction):
+        """Head (wan_video_dit.py:344-358) + unpatchify, and the prediction from the collected aggregator layers."""
+        cfg, ops, sh = self.cfg, self.ops, self.shard
+        F, h, w, L = st.F, st.h, st.w, st.L
+        xn = ops.layernorm(st.xs, scale=self.head_mod[1] + st.t, shift=self.head_mod[0] + st.t, eps=cfg.eps)
         hd_out = ops.linear(xn, self.head, out_f32=True)                                       # [L(local), 64]
         if sh is not None:
             hd_out = sh.all_gather_rows(hd_out, sh.dit_counts)
-        outs = [ops.unpatchify(hd_out[i * L:(i + 1) * L], F, h, w, x.dtype) for i in range(nb)]
+        outs = [ops.unpatchify(hd_out[i * L:(i + 1) * L], F, h, w, out_dtype) for i in range(st.nb)]
         if return_prediction:
             if sh is not None:
                 outputs = {k: sh.gather_frames(v) for k, v in outputs.items()}

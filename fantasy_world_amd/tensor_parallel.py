@@ -372,65 +372,28 @@ class TPFusionEngine(FusionEngine):
 
     def _forward(self, x, timestep, contexts, clip_feature, y, plucker_fea, plucker_context_lens, uncond, return_prediction,
                  camera_token, control_camera_latents_input, collect):
-        cfg, ops = self.cfg, self.ops
-        assert len(contexts) == 1 and x.shape[0] == 1
-        self._nb = 1
-        F, H2, W2 = x.shape[2:]
-        h, w = H2 // 2, W2 // 2
-        hw = h * w
-        L = F * hw
-        P = cfg.n_special + hw
-        tabs = self._get_tables(F, h, w)
+        cfg = self.cfg
+        assert len(contexts) == 1 and x.shape[0] == 1 and self.shard is None
+        # embeddings, patchify, bridge and head are replicated: the unsharded engine's own code (engine.py _prologue ...)
+        st = self._prologue(x, timestep, contexts, clip_feature, y, plucker_fea, control_camera_latents_input)
+        F, P, tabs, xs, t_mod, e0 = st.F, st.P, st.tabs, st.xs, st.t_mod, st.e0
+        ctx_txt, ctx_img, plucker = st.ctx_txt, st.ctx_img, st.plucker
         per_block = None if collect is None else collect.get("per_block")
 
-        # embeddings, patchify: replicated (same code as the unsharded engine, engine.py _forward)
-        sin = ops.sinusoid(timestep, cfg.freq_dim)
-        t = ops.linear_f32(ops.linear_f32(sin, self.time0, act="silu"), self.time2)
-        t_mod = ops.linear_f32(t, self.timep, silu_in=True).view(6, cfg.dim)
-        ev = ops.linear_f32(ops.linear_f32(sin, self.vtime0, act="silu"), self.vtime2)
-        e0 = ops.linear_f32(ev, self.vtimep, silu_in=True).view(6, cfg.vggt_dim)
-        c = contexts[0]
-        ctx_txt = self.invariants.get("ctx_txt", (c,), lambda: ops.linear(
-            ops.linear(ops.to_act(c[0]), self.text0, act="gelu_tanh"), self.text2))
-        ctx_img = None
-        if cfg.has_image_input:
-            def image_ctx():
-                ci = ops.layernorm(ops.to_act(clip_feature[0]), w=self.img_ln0[0], b=self.img_ln0[1], eps=1e-5)
-                ci = ops.linear(ops.linear(ci, self.img1, act="gelu_erf"), self.img3)
-                return ops.layernorm(ci, w=self.img_ln4[0], b=self.img_ln4[1], eps=1e-5)
-            ctx_img = self.invariants.get("ctx_img", (clip_feature,), image_ctx)
-        use_y = y is not None and (cfg.has_image_input or cfg.control_adapter)
-        patches = ops.patchify(x, y if use_y else None, self.kpatch)
-        ycam = None
-        if cfg.control_adapter and control_camera_latents_input is not None:
-            ycam = self._control_features(control_camera_latents_input, F, h, w)
-        plucker = None
-        if plucker_fea is not None and cfg.camera_adapter and not self._plucker_all_zero(plucker_fea):
-            plucker = self.invariants.get("plucker_rows", (plucker_fea,), lambda: ops.to_act(plucker_fea[0]))
-        xs = ops.linear(patches, self.patch, res=ycam, out_f32=True)
-
         for b in range(cfg.start_index):
-            blk, st = self.dit[b], {}
-            _drain(self._tp_dit_attn(blk, xs, ctx_txt, ctx_img, t_mod, tabs, plucker, st))
-            _drain(self._tp_dit_ffn(blk, xs, st["mod"]))
+            blk, sd = self.dit[b], {}
+            _drain(self._tp_dit_attn(blk, xs, ctx_txt, ctx_img, t_mod, tabs, plucker, sd))
+            _drain(self._tp_dit_ffn(blk, xs, sd["mod"]))
             if per_block is not None:
                 per_block("x", b, xs)
         if collect is not None:
             collect["x_after_pcb"] = xs.clone()
 
-        ptok = ops.linear(ops.cast_act(xs), self.proj)
-        tok = ops.assemble_tokens(ptok, self.special, F, hw)
-        if camera_token is not None:
-            ct = ops.to_act(camera_token[0])
-            ct = torch.cat([ct, ct[:1].expand(3, -1)], dim=0).reshape(-1, 36)
-            cam = ops.linear(ops.linear(_pad_to(ct, 1, 64), self.camtok0, act="gelu_erf"), self.camtok2, out_f32=True)
-            tok.view(F, P, cfg.vggt_dim)[:, 0, :] = cam
+        tok, _ = self._entry_tokens(st, camera_token)
         if collect is not None:
             collect["tokens_in"] = tok.clone()
 
-        need = set()
-        if return_prediction:
-            need = set(self.heads_cfg.layer_idx if self.heads_cfg is not None else (7, 11, 17, 23)) | {cfg.n_irg - 1}
+        need = self._layers_for_heads(return_prediction)
         outputs = {}
         for i in range(cfg.n_irg):
             fb, blk, gb = self.frame[i], self.dit[cfg.start_index + i], self.glob[i]
@@ -457,12 +420,4 @@ class TPFusionEngine(FusionEngine):
         if collect is not None:
             collect["x_final"] = xs.clone()
             collect["tokens_final"] = tok.clone()
-
-        xn = ops.layernorm(xs, scale=self.head_mod[1] + t, shift=self.head_mod[0] + t, eps=cfg.eps)
-        hd_out = ops.linear(xn, self.head, out_f32=True)
-        outs = [ops.unpatchify(hd_out, F, h, w, x.dtype)]
-        if return_prediction:
-            if self.heads_cfg is None:
-                return outs, outputs
-            return outs, self.geometry_heads().predict(outputs, F, h, w, patch_start_idx=cfg.n_special)
-        return outs, None
+        return self._epilogue(st, x.dtype, outputs, return_prediction)
