@@ -109,8 +109,9 @@ class CfgPairing:
     and group 1 the negative forward, the two noise predictions are exchanged with one all-gather (4 MB), the positive one is
     returned and the negative one is kept for the call that follows; that call is recognised by identity (same latents object,
     same timestep object, the learned negative context) and answered from the stash.  Anything else -- another prompt,
-    uncond=True, return_prediction=True (the last step needs the positive pass's geometry on every rank) -- takes the plain
-    path and re-learns.  Every rank runs the same script on the same inputs, so every rank takes the same branch and returns
+    uncond=True, and with rank groups return_prediction=True (the last step needs the positive pass's geometry on every rank)
+    -- takes the plain path and re-learns (the single-GPU merged pass serves the last step too: it returns the positive
+    sample's prediction).  Every rank runs the same script on the same inputs, so every rank takes the same branch and returns
     the same tensors as a single-GPU run."""
 
     def __init__(self, topo=None):
@@ -123,21 +124,23 @@ class CfgPairing:
 
     def run(self, forward, x, timestep, context, uncond, return_prediction, forward_pair=None):
         """forward(context, want_prediction) -> (out, prediction) on this rank's sequence-shard group;
-        forward_pair(ctx_first, ctx_second) -> (out_first, out_second): the merged pass (single GPU only)."""
-        plain = uncond or return_prediction
+        forward_pair(ctx_first, ctx_second, want_prediction) -> (out_first, out_second, prediction of the first): the merged pass
+        (single GPU only)."""
+        plain = uncond or (return_prediction and self.topo is not None)
         st = self.stash
         if st is not None and not plain and st[0] is x and st[1] is timestep and self.pair is not None and context is self.pair[1]:
             self.stash = None
             return st[2], None
         self.stash = None
         if not plain and self.pair is not None and context is self.pair[0]:
+            pred = None
             if self.topo is not None:
                 out, _ = forward(self.pair[self.topo.cfg_rank], False)
                 first, second = self.topo.gather_cfg(out)
             else:
-                first, second = forward_pair(self.pair[0], self.pair[1])
+                first, second, pred = forward_pair(self.pair[0], self.pair[1], return_prediction)
             self.stash = (x, timestep, second)
-            return first, None
+            return first, pred
         if self.last is not None and self.last[0] is x and self.last[1] is timestep and self.last[2] is not context:
             self.pair = (self.last[2], context)
         self.last = (x, timestep, context)
@@ -221,11 +224,11 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                                         plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
                                         uncond=uncond, return_prediction=want_prediction, camera_token=camera_token,
                                         control_camera_latents_input=control_camera_latents_input)
-        def forward_pair(ctx_a, ctx_b):
-            a, b, _ = engine.joint_forward_pair(x, timestep, ctx_a, ctx_b, clip_feature=clip_feature, y=y, plucker_fea=plucker_fea,
-                                                plucker_context_lens=plucker_context_lens, uncond=uncond, camera_token=camera_token,
-                                                control_camera_latents_input=control_camera_latents_input)
-            return a, b
+        def forward_pair(ctx_a, ctx_b, want_prediction):
+            return engine.joint_forward_pair(x, timestep, ctx_a, ctx_b, clip_feature=clip_feature, y=y, plucker_fea=plucker_fea,
+                                             plucker_context_lens=plucker_context_lens, uncond=uncond,
+                                             return_prediction=want_prediction, camera_token=camera_token,
+                                             control_camera_latents_input=control_camera_latents_input)
         if pairing is not None:
             out, outputs = pairing.run(forward, x, timestep, context, uncond, return_prediction, forward_pair)
         else:

@@ -232,7 +232,7 @@ def build_reference_wan21(cfg, weights=None, heads_cfg=None):
     return model
 
 
-def build_reference_wan22(cfg, weights=None):
+def build_reference_wan22(cfg, weights=None, heads_cfg=None):
     """Build the reference FantasyWorldFusionModel, Wan2.2-Fun-A14B-Control-Camera flavour (one expert), for `cfg`.
 
     Mirrors FantasyWorld/fusion/model_wan22.py:122-229 without checkpoints, LoRA or "cuda": diffsynth_wan22 WanModel with the
@@ -242,6 +242,7 @@ def build_reference_wan22(cfg, weights=None):
     from FantasyWorld.fusion.model_wan22 import FantasyWorldFusionModel
     from FantasyWorld.fusion.layer.block import IRGBlock
     from FantasyWorld.diffsynth_wan22.models.wan_video_dit import WanModel, precompute_freqs_cis_3d
+    from FantasyWorld.diffsynth_wan22.schedulers.flow_match import FlowMatchScheduler
     from FantasyWorld.vggt.models.vggt import VGGT
 
     torch.manual_seed(0)
@@ -255,10 +256,13 @@ def build_reference_wan22(cfg, weights=None):
                        require_clip_embedding=False)
         vggt = VGGT(enable_camera=True, enable_depth=True, enable_point=True, enable_track=False,
                     DPT_patch_size=16)
+        if heads_cfg is not None:
+            _swap_heads(vggt, heads_cfg)
     if weights is not None:
         dit.freqs = precompute_freqs_cis_3d(cfg.dim // cfg.num_heads)
         vggt.aggregator.freqs = torch.zeros(1)
-    model.pipe = _FakePipe(dit, None)
+    # the pipeline's scheduler (diffsynth_wan22/pipelines/wan_video_new.py:36)
+    model.pipe = _FakePipe(dit, FlowMatchScheduler(shift=5, sigma_min=0.0, extra_one_step=True))
     model.vggt = vggt
     n_irg = cfg.num_layers - cfg.start_index
     vggt.aggregator.frame_blocks = nn.ModuleList(list(vggt.aggregator.frame_blocks)[:n_irg])
@@ -290,6 +294,21 @@ def build_reference_wan22(cfg, weights=None):
         load_named_weights(model, weights)
     model.eval()
     return model
+
+
+def build_reference_wan22_sampler(model_high, model_low, *, seed=0, cfg_scale=5.0, timestep_boundary=900, device="cpu",
+                                  dtype=torch.float32):
+    """The reference's Wan2.2 sampler object (inference_wan22.py:40 FantasyWorldSampler) around two already-built experts, WITHOUT
+    its __init__ (checkpoints, MoGe, "cuda"): only the attributes generate_video_with_dual_models (inference_wan22.py:164-283)
+    reads.  The method itself is the reference's, unmodified."""
+    install_stubs()
+    import inference_wan22                                    # the reference's script, from REFERENCE_ROOT (its main() is guarded)
+    assert os.path.realpath(inference_wan22.__file__).startswith(os.path.realpath(REFERENCE_ROOT)), inference_wan22.__file__
+    s = object.__new__(inference_wan22.FantasyWorldSampler)
+    s.model_high, s.model_low = model_high, model_low
+    s.base_seed, s.cfg_scale, s.timestep_boundary = seed, cfg_scale, timestep_boundary
+    s.device, s.torch_dtype = device, dtype
+    return s
 
 
 class _nullctx:

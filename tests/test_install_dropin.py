@@ -133,6 +133,60 @@ def test_install_on_reference_wan22_model(case_w22):
     uninstall(model)
 
 
+def _wan22_two_experts(num_layers=3):
+    """Two Wan2.2 experts (different weights) with the narrow geometry heads; inputs for generate_video_with_dual_models."""
+    from fantasy_world_amd import config as fwc, synth
+    cfg = fwc.plumbing22(num_layers=num_layers, start_index=1)
+    hc = fwc.HeadsConfig.e2e_small()
+    W = []
+    for seed in (0, 1):
+        w = synth.make_weights(cfg, seed=seed)
+        w.update(synth.make_heads_weights(hc, seed=seed))
+        W.append(w)
+    f, h2, w2 = 2, 8, 12
+    ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=900.0, text_len=512)
+    frames = 4 * (f - 1) + 1
+    kw = dict(context_pos=ins["context"], context_neg=ins["context_neg"], y=ins["y"], height=8 * h2, width=8 * w2,
+              num_frames=frames, sample_steps=4, plucker_embedding=synth.make_plucker(frames, 8 * h2, 8 * w2))
+    return cfg, hc, W, kw
+
+
+def test_install_under_the_reference_wan22_dual_expert_loop():
+    """The Wan2.2 sampler's OWN loop (inference_wan22.py:164-283 generate_video_with_dual_models, unmodified): it picks the
+    high-noise or the low-noise expert per step by the timestep boundary and calls that model's joint_forward twice (CFG), with
+    return_prediction on the last step.  install() on BOTH experts: two engines side by side, each learning its own CFG pair on
+    the first step it serves and merging from its second; latents and the prediction dict of the plain reference loop."""
+    from conftest import PRED_KEYS
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install, uninstall
+    cfg, hc, W, kw = _wan22_two_experts()
+    high = ref_harness.build_reference_wan22(cfg, weights=W[0], heads_cfg=hc)
+    low = ref_harness.build_reference_wan22(cfg, weights=W[1], heads_cfg=hc)
+    del W
+    # shift-5 schedule over 4 steps: timesteps 1000, 937.5, 833.3, 625 -> boundary 900: two steps on each expert
+    sampler = ref_harness.build_reference_wan22_sampler(high, low, seed=3, cfg_scale=5.0, timestep_boundary=900)
+    with torch.no_grad():
+        want, wpred = sampler.generate_video_with_dual_models(**kw)
+    engines = [install(m, ops=TorchRefOps()) for m in (high, low)]
+    passes = ([], [])
+    for eng, log in zip(engines, passes):
+        orig = eng._forward
+        eng._forward = (lambda orig, log: lambda x, t, contexts, *a, **k: (log.append(len(contexts)), orig(x, t, contexts, *a, **k))[1])(orig, log)
+    with torch.no_grad():
+        got, pred = sampler.generate_video_with_dual_models(**kw)            # the same call, both experts on the engine
+    assert passes == ([1, 1, 2], [1, 1, 2]), passes                          # per expert: learn the pair, then one merged pass
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert rel_l2(got, want) < 5e-5
+    for k in PRED_KEYS:
+        assert pred[k].shape == wpred[k].shape and rel_l2(pred[k], wpred[k]) < 1e-4, k
+    for m in (high, low):
+        uninstall(m)
+    with torch.no_grad():
+        back, _ = sampler.generate_video_with_dual_models(**kw)
+    assert torch.equal(back, want)
+
+
 def test_install_returns_prediction_dict_on_last_step(case_pred):
     """return_prediction=True (the last sampling step, M21:303-305): the rebound joint_forward returns the same dict as
     the reference's vggt._head_predction, computed by fantasy_world_amd.heads."""

@@ -150,6 +150,43 @@ def test_install_on_reference_wan22_model_on_hip(case_w22, parity):
     parity.check("ref_on_gpu/wan22/hip_vs_golden", rel_l2(got.float(), c.golden["noise_pred"]), 8e-3)
 
 
+def test_reference_wan22_dual_expert_loop_runs_on_hip_path(parity):
+    """The Wan2.2 sampler's own loop (inference_wan22.py:164-283 generate_video_with_dual_models, unmodified; boundary 900: two
+    steps on the high-noise expert, two on the low-noise one, return_prediction on the last) with install() on BOTH experts and
+    the HIP op set, against the same loop on the reference itself (PyTorch-ROCm, fp32).  Two engines side by side on one device;
+    each learns its CFG pair on its first step and runs the merged pass on its second (the last one with the prediction)."""
+    from oracle import ref_harness
+    from fantasy_world_amd import install, uninstall
+    from fantasy_world_amd.hip_ops import HipOps
+    from test_install_dropin import _wan22_two_experts
+    cfg, hc, W, kw = _wan22_two_experts()
+    high = _to_dev(ref_harness.build_reference_wan22(cfg, weights=W[0], heads_cfg=hc), torch.float32)
+    low = _to_dev(ref_harness.build_reference_wan22(cfg, weights=W[1], heads_cfg=hc), torch.float32)
+    del W
+    kw = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    sampler = ref_harness.build_reference_wan22_sampler(high, low, seed=3, cfg_scale=5.0, timestep_boundary=900, device=DEV)
+    with torch.no_grad():
+        want, wpred = sampler.generate_video_with_dual_models(**kw)
+    torch.cuda.synchronize()
+    ops = HipOps(DEV)
+    engines = [install(m, ops=ops) for m in (high, low)]
+    passes = ([], [])
+    for eng, log in zip(engines, passes):
+        orig = eng._forward
+        eng._forward = (lambda orig, log: lambda x, t, contexts, *a, **k: (log.append(len(contexts)), orig(x, t, contexts, *a, **k))[1])(orig, log)
+    got, pred = sampler.generate_video_with_dual_models(**kw)
+    torch.cuda.synchronize()
+    for m in (high, low):
+        uninstall(m)
+    assert passes == ([1, 1, 2], [1, 1, 2]), passes
+    assert got.shape == want.shape and got.dtype == want.dtype
+    # four CFG-combined steps carry ~1e-2 of the forwards' 2.7e-3 (see test_reference_generate_video_runs_on_hip_path)
+    parity.check("ref_on_gpu/wan22_dual_expert_loop/latents_hip_vs_ref_fp32", rel_l2(got, want), 4e-2)
+    for k in PRED_KEYS:
+        assert pred[k].shape == wpred[k].shape
+        parity.check(f"ref_on_gpu/wan22_dual_expert_loop/{k}", rel_l2(pred[k].float(), wpred[k].float()), 6e-2)
+
+
 @pytest.mark.parametrize("M,N,K,amp", [(256, 384, 512, 3.0), (4096, 5120, 5120, 1.0), (2048, 13824, 5120, 30.0)])
 def test_fp8_linear_against_the_real_scaled_mm(M, N, K, amp, parity):
     """A19 with the REAL checker: AutoWrappedLinear.forward -> fp8_linear -> torch._scaled_mm (layers.py:115-151,154-166) on this
