@@ -38,6 +38,8 @@ struct AttnArgs {
     // and its softmax shifts (fp32, [bh][qb][run][256 rows][HD + 2]) and attention_combine_kernel merges the runs.
     float* part;
     int nsplit, tiles_per_split;
+    int prio;           // experiment (FW_ATTN_VAR bits 8-9): 1 = s_setprio 1 for waves 4..7, 2 = for waves 0..3, before the tile loop;
+                        // measured +-0 on every shape (profiles/r03/microbench_attention_static_priority.txt), default 0
 };
 
 template <int HD>
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks], qf[ks], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * ks + 1], qf[ks], s1, 0, 0, 0);
     }
+    if ((p.prio == 1 && grp == 1) || (p.prio == 2 && grp == 0)) __builtin_amdgcn_s_setprio(1);
     if (grp == 1) FW_ABARRIER();
 
     int t = 0;
@@ -944,6 +947,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         }
     };
 
+    if ((p.prio == 1 && wave >= NW / 2) || (p.prio == 2 && wave < NW / 2)) __builtin_amdgcn_s_setprio(1);
     // ---- prologue ---------------------------------------------------------------------------------------------------
     issue_k(0, 0);
     issue_k(min(1, nt - 1), 1);
@@ -1292,6 +1296,7 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     p.scale_log2 = prescaled ? 1.0f : scale * 1.4426950408889634f; p.accumulate = (flags & FW_ATTN_ACCUMULATE) ? 1 : 0;
     p.nqb = (Lq + QB - 1) / QB;
     p.part = nullptr; p.nsplit = 1; p.tiles_per_split = 0;
+    p.prio = (fw_get_option(FW_OPT_ATTN_VAR) >> 8) & 3;
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -1322,7 +1327,7 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
             return (int)hipGetLastError();
         }
     }
-    int var = fw_get_option(FW_OPT_ATTN_VAR);           // 0 = first kernel (generic); 64.. = two-segment ping-pong; 128.. = single stream
+    int var = fw_get_option(FW_OPT_ATTN_VAR) & 255;     // 0 = first kernel (generic); 64.. = two-segment ping-pong; 128.. = single stream
     // 192 = per-head-dim choice among the pre-scaled kernels (microbench, profiles/r01/attention_sp_ablation.txt): the
     // single-stream kernel for hd 128 and hd 64, the two-segment ping-pong for hd 96
     // round 3: hd 128 / hd 64 on the ring-unrolled form of the single-stream kernel (193): -2.4 % / -4.6 % on one box

@@ -70,8 +70,9 @@ int fw_abi_version(void);
                                    loop unrolled by the LDS ring depth (193; ring slots are compile-time, no address VALU in the
                                    loop) for hd 128 / 64, two-segment ping-pong (64) for hd 96.  129 = single-stream, run-time
                                    ring slots (the round-2 default); 131 / 195 = the same two with one 64-row wave per SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
-                                   WITHOUT the pre-scaled flag get).  fw_attention_fp8: 8 = its in-phase kernel, anything else =
-                                   its two-group ping-pong kernel */
+                                   WITHOUT the pre-scaled flag get).  Bits 8-9 (added to any of the above): static wave priority
+                                   before the tile loop, 256 = waves 4..7, 512 = waves 0..3 (measured +-0, default off).
+                                   fw_attention_fp8: 8 = its in-phase kernel, anything else = its two-group ping-pong kernel */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
 
