@@ -161,7 +161,6 @@ def main():
 
     import torch
     from fantasy_world_amd import config as fwc, synth, parallel
-    from fantasy_world_amd.engine import FusionEngine
     from fantasy_world_amd.hip_ops import HipOps
     from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step, denoise_step_dual
 

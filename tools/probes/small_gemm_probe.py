@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fantasy_world_amd.hip_ops import HipOps, Linear
 ops = HipOps("cuda:0")
 g = torch.Generator(device="cuda").manual_seed(0)
