@@ -156,6 +156,36 @@ def test_gemm_rows_do_not_depend_on_their_tile(ops, N, K, act):
         assert torch.equal(both[i * M:(i + 1) * M], alone), f"sample {i}"
 
 
+@pytest.mark.parametrize("N,K,tag", [(15360, 5120, "qkv"), (13824, 5120, "ffn0"), (5120, 13824, "ffn2")])
+def test_gemm_full_size_properties(ops, N, K, tag, parity):
+    """BASELINE config-2 shapes (M = L = 32760 rows; every tile, every k-slab of the kernel the forward runs), two size-independent
+    properties instead of a CPU reference:
+      * selection, BIT-EXACT: with one-hot rows (row m has a single 1.0 at column j(m)) the GEMM returns W[:, j(m)] + bias -- every
+        product is exact and every other term is 0, so fp32 out equals the gathered weights bit for bit and bf16 out their rounding;
+        a wrong row / column / k-slab address anywhere in the grid shows;
+      * a checksum of checksums on random data: sum_mn out[m, n] = sum_k (sum_m x[m, k]) (sum_n W[n, k]) + M sum_n b[n], in fp64."""
+    M = 32760
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+    lin = ops.pack_linear(w.float().cpu(), b.cpu())
+    j = (torch.arange(M, device="cuda") * 7919 + 13) % K
+    x = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    x[torch.arange(M, device="cuda"), j] = 1.0
+    want = w.float().t()[j] + b                                     # [M, N] fp32, exact
+    got = ops.linear(x, lin, out_f32=True)
+    assert torch.equal(got, want)
+    got16 = ops.linear(x, lin)
+    assert torch.equal(got16, want.to(torch.bfloat16))
+    del got, got16, want, x
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    out = ops.linear(x, lin, out_f32=True)
+    total = out.double().sum().item()
+    expect = (x.double().sum(0) * w.double().sum(0)).sum().item() + M * b.double().sum().item()
+    scale = out.double().abs().sum().item()
+    parity.check(f"op/gemm_full_size_checksum/{tag}", abs(total - expect) / scale, 1e-6)
+
+
 def test_gemm_rejects_bad_k(ops):
     x = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
     from fantasy_world_amd.hip_ops import Linear
