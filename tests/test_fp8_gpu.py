@@ -81,6 +81,33 @@ def test_fp8_pingpong_kernel_matches_torch_statement(ops, ref, M, N, K, parity):
     assert (got32.cpu() - want).abs().max() < 1e-3 * want.abs().max()
 
 
+@pytest.mark.parametrize("N,K,tag", [(15360, 5120, "qkv"), (5120, 13824, "ffn2")])
+def test_fp8_gemm_full_size_properties(ops, N, K, tag, parity):
+    """BASELINE config-2 shapes (M = 32760) through the fp8 linear, by size-independent properties: one-hot rows quantise exactly
+    (row maximum 1 -> scale_a = 1, 1.0 is an e4m3 value), so the GEMM must return the e4m3-cast weights W8[:, j(m)] BIT FOR BIT in
+    fp32 and their rounding in bf16 -- every tile and every 128-wide k-slab of the scaled-MFMA kernel; and a checksum of checksums
+    on random data against fp64 sums of the quantised operands."""
+    M = 32760
+    g = torch.Generator(device="cuda").manual_seed(6)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    lin = ops.pack_linear_fp8(w.float().cpu(), None)
+    w8 = lin.w.view(torch.float8_e4m3fn).float()[:N, :K]
+    j = (torch.arange(M, device="cuda") * 7919 + 13) % K
+    x = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    x[torch.arange(M, device="cuda"), j] = 1.0
+    want = w8.t()[j]
+    got = ops.linear_fp8(x, lin, out_f32=True)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.linear_fp8(x, lin), want.to(torch.bfloat16))
+    del got, want, x
+    x = (torch.randn(M, K, device="cuda", generator=g) * 2.0).to(torch.bfloat16)
+    xq, sa = ops.quantize_fp8_rows(x)
+    out = ops.linear_fp8(x, lin, out_f32=True)
+    xs = xq.view(torch.float8_e4m3fn).float().double() * sa.double().view(-1, 1)          # what the GEMM multiplies: x8 * scale_a per row
+    expect = (xs.sum(0) * w8.double().sum(0)).sum().item()
+    parity.check(f"op/fp8_gemm_full_size_checksum/{tag}", abs(out.double().sum().item() - expect) / out.double().abs().sum().item(), 1e-6)
+
+
 def test_fp8_linear_fused_epilogue(ops, ref, parity):
     """The fp8 linear with the bf16 linear's epilogue (act -> per-column affine -> + fp32 residual in place), both kernels."""
     for (M, N, K) in [(2560, 1024, 1024), (300, 320, 256)]:
