@@ -464,6 +464,57 @@ def test_qk_prep_ln_head_rope2d(ops, ref, parity, request):
     parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
 
 
+def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity):
+    """BASELINE config-2 sizes for the row-wise passes around the GEMMs (every row is independent, so a sample of rows pins the
+    launch at full size against the CPU oracle ops): the modulated LayerNorm of the fp32 DiT stream [32760, 5120], the affine +
+    modulated LayerNorm of the VGGT stream [32865, 1024], the DiT q/k pass (RMSNorm over 5120 + interleaved 3-D RoPE + q scale) on
+    [32760, 5120] and the VGGT q/k pass (per-head LayerNorm + 2-D RoPE) on two whole frames of [32865, 1024]."""
+    from fantasy_world_amd import rope
+    g = torch.Generator(device="cuda").manual_seed(71)
+    L, L2, P = 32760, 32865, 1565
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, 4095, 4096, 8191, 16384, 20000, 32503, 32758, 32759])
+    # LayerNorm, DiT stream
+    x = torch.randn(L, 5120, device="cuda", generator=g) * 2 + 0.3
+    sc, sh = rnd(5120, seed=72, scale=0.3), rnd(5120, seed=73, scale=0.3)
+    got = ops.layernorm(x, scale=sc.cuda(), shift=sh.cuda(), eps=1e-6)
+    want = ref.layernorm(x[rows.cuda()].cpu(), scale=sc, shift=sh, eps=1e-6)
+    parity.check("op/full_size_rows/layernorm_mod_5120", rel_l2(got[rows.cuda()].float(), want), 4e-3)
+    # a constant row has zero variance: the output is the shift, exactly (values with exact fp32 sums)
+    x[rows.cuda()] = 0.5
+    got = ops.layernorm(x, scale=sc.cuda(), shift=sh.cuda(), eps=1e-6)
+    assert torch.equal(got[rows.cuda()].cpu(), sh.to(torch.bfloat16).expand(len(rows), -1))
+    del x, got
+    # LayerNorm, VGGT stream (affine + modulation)
+    t = torch.randn(L2, 1024, device="cuda", generator=g)
+    w, b = 1 + rnd(1024, seed=74, scale=0.1), rnd(1024, seed=75, scale=0.1)
+    sc, sh = rnd(1024, seed=76, scale=0.3), rnd(1024, seed=77, scale=0.3)
+    rows2 = torch.cat([rows, torch.tensor([32760, 32864])])
+    got = ops.layernorm(t, w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), 1e-5)
+    want = ref.layernorm(t[rows2.cuda()].cpu(), w, b, sc, sh, 1e-5)
+    parity.check("op/full_size_rows/layernorm_affine_mod_1024", rel_l2(got[rows2.cuda()].float(), want), 4e-3)
+    del t, got
+    # DiT q pass: 40 heads x 128, full-width RMSNorm, 3-D RoPE, q pre-scale
+    heads, hd = 40, 128
+    tab = rope.rope3d_table(hd, 21, 30, 52)
+    q = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    nw = 1 + rnd(heads * hd, seed=78, scale=0.1)
+    qr = q[rows.cuda()].float().cpu()
+    ref.qk_prep(qr, heads, hd, "rms_full", nw, None, 1e-6, "interleaved", tab[rows], out_scale=ops.q_scale(hd))
+    ops.qk_prep(q, heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab.cuda(), out_scale=ops.q_scale(hd))
+    parity.check("op/full_size_rows/qk_prep_rms_rope3d", rel_l2(q[rows.cuda()].float(), qr), 4e-3)
+    del q
+    # VGGT k pass: 16 heads x 64, per-head LayerNorm, 2-D RoPE with table row = row % P: frames 0 and 20 whole
+    heads, hd = 16, 64
+    tab2 = rope.rope2d_table(hd, 30, 52, 5)
+    k = torch.randn(L2, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    nw, nb = 1 + rnd(hd, seed=79, scale=0.1), rnd(hd, seed=80, scale=0.1)
+    fr = torch.cat([torch.arange(0, P), torch.arange(20 * P, 21 * P)])
+    kr = k[fr.cuda()].float().cpu()
+    ref.qk_prep(kr, heads, hd, "ln_head", nw, nb, 1e-5, "half2d", tab2)
+    ops.qk_prep(k, heads, hd, "ln_head", nw.cuda(), nb.cuda(), 1e-5, "half2d", tab2.cuda())
+    parity.check("op/full_size_rows/qk_prep_ln_head_rope2d", rel_l2(k[fr.cuda()].float(), kr), 4e-3)
+
+
 def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref, parity, request):
     """bicross k: no norm, RoPE-3D hd=96 with 5 un-rotated special tokens per frame (DIT21:105-132)."""
     from fantasy_world_amd import rope
