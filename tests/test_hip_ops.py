@@ -186,6 +186,22 @@ def test_gemm_full_size_properties(ops, N, K, tag, parity):
     parity.check(f"op/gemm_full_size_checksum/{tag}", abs(total - expect) / scale, 1e-6)
 
 
+def test_empty_inputs(ops):
+    """Zero rows are a no-op with the right shapes (no launch with an empty grid, no error); zero KEYS have no softmax and are
+    refused by name."""
+    lin = ops.pack_linear(rnd(256, 128, seed=1), torch.zeros(256))
+    e = torch.zeros(0, 128, dtype=torch.bfloat16, device="cuda")
+    k = bf(rnd(64, 128, seed=2)).cuda()
+    assert ops.linear(e, lin).shape == (0, 256)
+    assert ops.layernorm(torch.zeros(0, 1024, device="cuda"), eps=1e-6).shape == (0, 1024)
+    assert ops.attention(e, k, k, 1, 128).shape == (0, 128)
+    ops.qk_prep(e, 1, 128, "rms_full", torch.ones(128, device="cuda"), None, 1e-6)
+    assert ops.residual_add(torch.zeros(0, 256, device="cuda"), torch.zeros(0, 256, dtype=torch.bfloat16, device="cuda")).shape == (0, 256)
+    with pytest.raises(RuntimeError, match="Lk must be > 0"):
+        ops.attention(k, e, e, 1, 128)
+    torch.cuda.synchronize()
+
+
 def test_gemm_rejects_bad_k(ops):
     x = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
     from fantasy_world_amd.hip_ops import Linear
