@@ -164,11 +164,24 @@ def main():
     from fantasy_world_amd.hip_ops import HipOps
     from fantasy_world_amd.sampler import FlowMatchScheduler, denoise_step, denoise_step_dual
 
+    # a multi-rank run that stops making progress (a collective one rank never issues) would otherwise sit silent until the caller's
+    # own limit: dump every thread's Python stack and exit non-zero instead.  FW_BENCH_WATCHDOG_S = seconds, 0 = off.
+    wd = float(os.environ.get("FW_BENCH_WATCHDOG_S", "0" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "2700"))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
+
     topo = parallel.init_topology()
     shard, rank, world, local = topo.shard, topo.rank, topo.world, topo.local
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = int(os.environ.get("FW_BENCH_DEVICE", local))     # debugging aid: several ranks on one GPU (with FW_DIST_BACKEND=gloo)
+    if os.environ.get("FW_DIST_BACKEND") == "gloo":
+        # gloo on CUDA tensors (the debugging aid above, never the measured path): with 2-rank shard groups the grouped q|k|v exchange
+        # -- a third collective issued while one is still in flight -- stops making progress inside gloo's device staging
+        # (profiles/r03/dryrun_ranks_small.txt: stacks from the watchdog); one exchange per attention completes.  RCCL runs a
+        # communicator's collectives in issue order on its own stream, where the same issue order on every rank is sufficient.
+        os.environ.setdefault("FW_SP_EXCHANGE_GROUPS", "1")
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
     ops = HipOps(dev)

@@ -15,6 +15,7 @@ Numerics: residual streams (DiT x, VGGT tokens) are kept in fp32 (the reference 
 the VGGT stream in fp32 after the first modulated block); matmul inputs are bf16, accumulation fp32; all
 normalisation statistics, softmax and rotary math are fp32 (tables from fp64).
 """
+import os
 import types
 from typing import Callable
 
@@ -116,7 +117,8 @@ class FusionEngine:
         self.heads_cfg = heads_cfg
         self._heads = None
         self._get = get
-        self.exchange_groups = 2       # head groups per DiT self-attention exchange under a sequence shard (1 = one exchange)
+        # head groups per DiT self-attention exchange under a sequence shard (1 = one exchange); FW_SP_EXCHANGE_GROUPS overrides
+        self.exchange_groups = int(os.environ.get("FW_SP_EXCHANGE_GROUPS", "2"))
         self.bicross_head_exchange = True    # sequence shard: head all-to-all for the bicross when its 12 heads divide (else row all-gathers)
         # Off by default: bench.py measures the reference's per-step work.  install() turns it on for real generations.
         self.invariants = _InvariantCache(cache_step_invariants)
