@@ -390,6 +390,8 @@ def main():
         out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if wd > 0:
+        faulthandler.cancel_dump_traceback_later()
     if world > 1:
         torch.distributed.destroy_process_group()
 
