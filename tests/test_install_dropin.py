@@ -133,22 +133,31 @@ def test_install_on_reference_wan22_model(case_w22):
     uninstall(model)
 
 
-def _wan22_two_experts(num_layers=3):
-    """Two Wan2.2 experts (different weights) with the narrow geometry heads; inputs for generate_video_with_dual_models."""
+def _wan22_two_experts(build):
+    """Two Wan2.2 experts (different weights) with narrow geometry heads, and the inputs of generate_video_with_dual_models.
+    Memory is the constraint here (the CPU suite shares one 62 GB container with the session-scoped cases; a 3-layer pair built side
+    by side took the process to 65 GB and the OOM killer): 1 PCB + 1 IRG block (0.7 B parameters per expert), head taps that read
+    layer 0 only, and the experts are built ONE AT A TIME through `build(cfg, weights, hc)` so that only one fp32 weight dictionary
+    exists at any moment."""
+    import gc
     from fantasy_world_amd import config as fwc, synth
-    cfg = fwc.plumbing22(num_layers=num_layers, start_index=1)
-    hc = fwc.HeadsConfig.e2e_small()
-    W = []
+    cfg = fwc.plumbing22(num_layers=2, start_index=1)
+    e2e = fwc.HeadsConfig.e2e_small()
+    hc = fwc.HeadsConfig(dim_in=e2e.dim_in, trunk_depth=e2e.trunk_depth, cam_heads=e2e.cam_heads, features=e2e.features,
+                         out_channels=list(e2e.out_channels), layer_idx=[0, 0, 0, 0], dpt_patch=e2e.dpt_patch)
+    experts = []
     for seed in (0, 1):
         w = synth.make_weights(cfg, seed=seed)
         w.update(synth.make_heads_weights(hc, seed=seed))
-        W.append(w)
+        experts.append(build(cfg, w, hc))
+        del w
+        gc.collect()
     f, h2, w2 = 2, 8, 12
     ins = synth.make_inputs(cfg, f, h2, w2, seed=1, timestep=900.0, text_len=512)
     frames = 4 * (f - 1) + 1
     kw = dict(context_pos=ins["context"], context_neg=ins["context_neg"], y=ins["y"], height=8 * h2, width=8 * w2,
               num_frames=frames, sample_steps=4, plucker_embedding=synth.make_plucker(frames, 8 * h2, 8 * w2))
-    return cfg, hc, W, kw
+    return experts[0], experts[1], kw
 
 
 def test_install_under_the_reference_wan22_dual_expert_loop():
@@ -160,10 +169,7 @@ def test_install_under_the_reference_wan22_dual_expert_loop():
     from oracle import ref_harness
     from oracle.ref_ops import TorchRefOps
     from fantasy_world_amd import install, uninstall
-    cfg, hc, W, kw = _wan22_two_experts()
-    high = ref_harness.build_reference_wan22(cfg, weights=W[0], heads_cfg=hc)
-    low = ref_harness.build_reference_wan22(cfg, weights=W[1], heads_cfg=hc)
-    del W
+    high, low, kw = _wan22_two_experts(lambda cfg, w, hc: ref_harness.build_reference_wan22(cfg, weights=w, heads_cfg=hc))
     # shift-5 schedule over 4 steps: timesteps 1000, 937.5, 833.3, 625 -> boundary 900: two steps on each expert
     sampler = ref_harness.build_reference_wan22_sampler(high, low, seed=3, cfg_scale=5.0, timestep_boundary=900)
     with torch.no_grad():
@@ -185,6 +191,9 @@ def test_install_under_the_reference_wan22_dual_expert_loop():
     with torch.no_grad():
         back, _ = sampler.generate_video_with_dual_models(**kw)
     assert torch.equal(back, want)
+    del engines, sampler, high, low
+    import gc
+    gc.collect()
 
 
 def test_install_returns_prediction_dict_on_last_step(case_pred):

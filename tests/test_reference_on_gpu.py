@@ -159,10 +159,8 @@ def test_reference_wan22_dual_expert_loop_runs_on_hip_path(parity):
     from fantasy_world_amd import install, uninstall
     from fantasy_world_amd.hip_ops import HipOps
     from test_install_dropin import _wan22_two_experts
-    cfg, hc, W, kw = _wan22_two_experts()
-    high = _to_dev(ref_harness.build_reference_wan22(cfg, weights=W[0], heads_cfg=hc), torch.float32)
-    low = _to_dev(ref_harness.build_reference_wan22(cfg, weights=W[1], heads_cfg=hc), torch.float32)
-    del W
+    high, low, kw = _wan22_two_experts(
+        lambda cfg, w, hc: _to_dev(ref_harness.build_reference_wan22(cfg, weights=w, heads_cfg=hc), torch.float32))
     kw = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
     sampler = ref_harness.build_reference_wan22_sampler(high, low, seed=3, cfg_scale=5.0, timestep_boundary=900, device=DEV)
     with torch.no_grad():
