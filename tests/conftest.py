@@ -267,3 +267,32 @@ class VaeCase:
 @pytest.fixture(scope="session", params=["vae_full_t3_4x6", "vae_full_t2_3x5"])
 def vae_case(request):
     return VaeCase(request.param)
+
+
+@pytest.fixture(autouse=True)
+def _collect_cycles_after_each_test():
+    """install() ties model -> rebound method -> closure -> engine -> modules into a reference cycle, and the cyclic collector
+    triggers on object COUNTS, not bytes: a few multi-GB tensors in a cycle stay resident for many tests.  Without this the CPU suite's
+    resident set ratchets 11 -> 56 GB across the install / engine tests (profiles/r03/pytest_cpu_rss_trace_before_gc_fixture.tsv) in a
+    62 GB container and ran into the OOM killer once."""
+    yield
+    import gc
+    gc.collect()
+
+
+# FW_TEST_RSS_LOG=<file>: append "nodeid <tab> RSS now (GB) <tab> peak RSS so far (GB)" after every test -- where the CPU suite's memory
+# goes (the build container has 62 GB; the suite once ran into the OOM killer).  Off by default.
+def pytest_runtest_teardown(item, nextitem):
+    path = os.environ.get("FW_TEST_RSS_LOG")
+    if not path:
+        return
+    import resource
+    now = 0.0
+    try:
+        with open("/proc/self/statm") as f:
+            now = int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e9
+    except OSError:
+        pass
+    peak = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    with open(path, "a") as f:
+        f.write(f"{item.nodeid}\t{now:.1f}\t{peak:.1f}\n")
