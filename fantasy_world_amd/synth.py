@@ -160,6 +160,40 @@ def make_weights(cfg: FWConfig, device="cpu", dtype=torch.float32, seed=0, bf16_
     return out
 
 
+class LazyWeights:
+    """name -> tensor mapping that draws each parameter on demand, ON `device` (same per-name generators as make_weights: the values
+    depend on (name, seed) only).  For the full-depth models -- 16 B parameters = 64 GB in fp32 -- where a materialised dictionary
+    next to the module tree that clones from it would double the footprint: bench.py packs straight from it, the full-depth parity
+    test (tests/test_full_depth_gpu.py) loads the reference module tree from it.  `specs`: one or more name -> (shape, init) tables
+    (weight_spec, heads_weight_spec, pose_encoder_weight_spec)."""
+
+    def __init__(self, *specs, device="cpu", seed=0, bf16_round=True):
+        self.spec = OrderedDict()
+        for s in specs:
+            self.spec.update(s)
+        self.device, self.seed, self.bf16_round = device, seed, bf16_round
+
+    def __contains__(self, name):
+        return name in self.spec
+
+    def __iter__(self):
+        return iter(self.spec)
+
+    def __len__(self):
+        return len(self.spec)
+
+    def keys(self):
+        return self.spec.keys()
+
+    def __getitem__(self, name):
+        shape, init = self.spec[name]
+        t = make_param(name, shape, init, device=self.device, dtype=torch.float32, seed=self.seed)
+        return t.to(torch.bfloat16).to(torch.float32) if self.bf16_round else t
+
+    def items(self):
+        return ((k, self[k]) for k in self.spec)
+
+
 def make_inputs(cfg: FWConfig, f: int, h2: int, w2: int, seed=1, device="cpu", dtype=torch.float32,
                 text_len=512, timestep=500.0):
     """Synthetic joint_forward inputs: latents [1,16,f,h2,w2], y [1,20,f,h2,w2] (4 mask + 16 latent
