@@ -119,19 +119,35 @@ class CfgPairing:
         # once, bit-identical to two calls) at the loop's first call, the second call is answered from the stash all the same
         self.topo = topo
         self.pair = None          # (first context, second context) of a step, learned
-        self.last = None          # (x, timestep, context) of the previous plain call
-        self.stash = None         # (x, timestep, second-context result) waiting for the second call
+        self.last = None          # (key of the previous plain call, its context)
+        self.stash = None         # (key, second-context result) waiting for the second call
 
-    def run(self, forward, x, timestep, context, uncond, return_prediction, forward_pair=None):
+    @staticmethod
+    def _key(x, timestep, cond):
+        """Identity AND in-place version of everything the two forwards of a step share: the latents, the timestep and every
+        conditioning tensor (clip_feature, y, camera_token, plucker_fea, plucker_context_lens, control_camera_latents_input).  The
+        stashed second result was computed from the FIRST call's conditioning: a loop that hands the negative pass different
+        conditioning, or that updates latents / timestep in place between the two calls, must not be answered from it."""
+        items = [x, timestep] + [cond[k] for k in sorted(cond)]
+        return tuple((id(t), t._version) if torch.is_tensor(t) else (None, t) for t in items), tuple(items)
+
+    @staticmethod
+    def _same(a, b):
+        return a is not None and b is not None and a[0] == b[0] and all(p is q for p, q in zip(a[1], b[1]))
+
+    def run(self, forward, x, timestep, context, uncond, return_prediction, forward_pair=None, cond=None):
         """forward(context, want_prediction) -> (out, prediction) on this rank's sequence-shard group;
         forward_pair(ctx_first, ctx_second, want_prediction) -> (out_first, out_second, prediction of the first): the merged pass
-        (single GPU only)."""
+        (single GPU only).  `cond`: name -> conditioning tensor of this call (part of the stash key)."""
         plain = uncond or (return_prediction and self.topo is not None)
+        key = self._key(x, timestep, cond or {})
         st = self.stash
-        if st is not None and not plain and st[0] is x and st[1] is timestep and self.pair is not None and context is self.pair[1]:
-            self.stash = None
-            return st[2], None
         self.stash = None
+        # the second call of a step: same latents / timestep / conditioning objects, unmodified since the first call, and the learned
+        # negative context.  A second call that asks for the prediction takes the plain path (the stash holds none for it).
+        if (st is not None and not plain and not return_prediction and self._same(st[0], key) and self.pair is not None
+                and context is self.pair[1]):
+            return st[1], None
         if not plain and self.pair is not None and context is self.pair[0]:
             pred = None
             if self.topo is not None:
@@ -139,11 +155,11 @@ class CfgPairing:
                 first, second = self.topo.gather_cfg(out)
             else:
                 first, second, pred = forward_pair(self.pair[0], self.pair[1], return_prediction)
-            self.stash = (x, timestep, second)
+            self.stash = (key, second)
             return first, pred
-        if self.last is not None and self.last[0] is x and self.last[1] is timestep and self.last[2] is not context:
-            self.pair = (self.last[2], context)
-        self.last = (x, timestep, context)
+        if self.last is not None and self._same(self.last[0], key) and self.last[1] is not context:
+            self.pair = (self.last[1], context)
+        self.last = (key, context)
         return forward(context, return_prediction)
 
 
@@ -230,7 +246,10 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                                              return_prediction=want_prediction, camera_token=camera_token,
                                              control_camera_latents_input=control_camera_latents_input)
         if pairing is not None:
-            out, outputs = pairing.run(forward, x, timestep, context, uncond, return_prediction, forward_pair)
+            out, outputs = pairing.run(forward, x, timestep, context, uncond, return_prediction, forward_pair,
+                                       cond=dict(clip_feature=clip_feature, y=y, camera_token=camera_token, plucker_fea=plucker_fea,
+                                                 plucker_context_lens=plucker_context_lens,
+                                                 control_camera_latents_input=control_camera_latents_input))
         else:
             out, outputs = forward(context, return_prediction)
         if not return_prediction:

@@ -356,3 +356,55 @@ def test_cfg_pairing_falls_back_when_the_pattern_breaks():
     assert pred == {"p": 1} and pairing.stash is None
     assert pairing.run(mk(x2), x2, t1, c, False, False)[0].item() == 32.0          # unknown prompt: plain, pair re-learned
     assert pairing.pair[0] is a and pairing.pair[1] is c
+
+
+def test_cfg_pairing_stash_is_keyed_on_all_conditioning_and_on_versions():
+    """the stashed negative result was computed with the FIRST call's clip_feature / y / camera_token / plucker_fea /
+    control tensor: a second call that hands over different conditioning, or that follows an IN-PLACE update of the latents or the
+    timestep, must take the plain path; so must a second call that asks for the prediction (the stash holds none).  Merged
+    single-GPU form (topo None) and the rank-group form."""
+    from fantasy_world_amd.install import CfgPairing
+
+    for topo in (None, type("Topo", (), {"cfg_rank": 0, "cfg_groups": 2, "gather_cfg": lambda self, o: (o, o + 100.0)})()):
+        log = []
+        pairing = CfgPairing(topo)
+        a, b = torch.zeros(1), torch.ones(1)
+
+        def run(x, t, ctx, cond, want=False):
+            def fwd(c, w):
+                log.append(("single", float(c), w))
+                return x + c + cond["y"], ({"p": 1} if w else None)
+
+            def fwd_pair(c0, c1, w):
+                log.append(("pair", w))
+                return x + c0 + cond["y"], x + c1 + cond["y"] + 100.0, ({"p": 2} if w else None)
+            return pairing.run(fwd, x, t, ctx, False, want, fwd_pair, cond=cond)
+
+        x, t = torch.tensor([10.0]), torch.tensor([0.5])
+        y1, y2 = torch.tensor([1.0]), torch.tensor([2.0])
+        cond1, cond2 = dict(y=y1, camera_token=None), dict(y=y2, camera_token=None)
+        run(x, t, a, cond1)
+        run(x, t, b, cond1)                                      # pair learned
+        assert pairing.pair is not None
+        # (1) regular step: second call from the stash
+        n = len(log)
+        run(x, t, a, cond1)
+        assert run(x, t, b, cond1)[0].item() == (112.0 if topo is None else 111.0) and len(log) == n + 1
+        # (2) the negative pass gets a different y: plain path, computed with ITS conditioning
+        n = len(log)
+        run(x, t, a, cond1)
+        out, _ = run(x, t, b, cond2)
+        assert out.item() == 13.0 and log[-1][0] == "single" and len(log) == n + 2
+        # (3) latents updated in place between the two calls (and the negative call of the previous step skipped)
+        run(x, t, a, cond1)
+        x.add_(1.0)
+        out, _ = run(x, t, b, cond1)
+        assert out.item() == 13.0 and log[-1][0] == "single"
+        # (4) timestep updated in place
+        run(x, t, a, cond1)
+        t.mul_(0.5)
+        assert run(x, t, b, cond1)[0].item() == 13.0 and log[-1][0] == "single"
+        # (5) the second call asks for the prediction: never (out, None) from the stash
+        run(x, t, a, cond1)
+        out, pred = run(x, t, b, cond1, want=True)
+        assert pred == {"p": 1} and out.item() == 13.0

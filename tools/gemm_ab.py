@@ -16,9 +16,13 @@ ap.add_argument("--kernels", default="4,5")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=6)
 ap.add_argument("--short-k", action="store_true", help="the K <= 2048 shapes of the VGGT / bicross / adapter GEMMs instead of the DiT ones")
+ap.add_argument("--square", action="store_true", help="the programming guide's calibration shapes 4096^3 / 8192^3 (+ the DiT qkv shape)")
+ap.add_argument("--uniform", action="store_true", help="uniform [-1, 1) operands (the guide's random fill) instead of normal")
 ap.add_argument("--zeros", action="store_true", help="zero-filled operands: the same instruction stream at a fraction of the switching power (DVFS check)")
 args = ap.parse_args()
-kernels = [tuple(int(v) for v in (k.split(":") + ["0"])[:2]) for k in args.kernels.split(",")]
+# "blas" = the vendor library behind torch.matmul on the SAME operands in the SAME interleaved rounds (a yardstick of what the box
+# sustains on this data; never linked or called by the product); plain shapes only (no fused residual epilogue)
+kernels = [("blas", 0) if k == "blas" else tuple(int(v) for v in (k.split(":") + ["0"])[:2]) for k in args.kernels.split(",")]
 ops = HipOps("cuda:0")
 g = torch.Generator(device="cuda").manual_seed(0)
 L = 32760
@@ -27,9 +31,12 @@ SHAPES = [(L, 15360, 5120, "qkv", False), (L, 13824, 5120, "ffn0", False), (L, 5
 if args.short_k:
     SHAPES = [(32865, 3072, 1024, "vggt qkv", False), (32865, 4096, 1024, "vggt fc1", False), (32865, 1024, 1024, "vggt proj+res", True),
               (L, 5120, 1152, "bicross out1+res", True), (32865, 1024, 1152, "bicross out2+res", True), (L, 2048, 2048, "adapter g1", False)]
+if args.square:
+    SHAPES = [(4096, 4096, 4096, "sq4096", False), (8192, 8192, 8192, "sq8192", False), (L, 15360, 5120, "qkv", False)]
+rnd = (lambda *s: torch.rand(*s, device="cuda", generator=g) * 2 - 1) if args.uniform else (lambda *s: torch.randn(*s, device="cuda", generator=g))
 for (M, N, K, tag, res) in SHAPES:
-    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
-    lin = Linear(torch.randn(N, K, device="cuda", generator=g).to(torch.bfloat16) * K ** -0.5, torch.zeros(N, device="cuda"))
+    x = rnd(M, K).to(torch.bfloat16)
+    lin = Linear(rnd(N, K).to(torch.bfloat16) * (1.0 if args.uniform else K ** -0.5), torch.zeros(N, device="cuda"))
     if args.zeros:
         x.zero_()
         lin.w.zero_()
@@ -39,9 +46,16 @@ for (M, N, K, tag, res) in SHAPES:
     times = {k: [] for k in kernels}
     for r in range(args.rounds):
         for k in kernels:
-            ops.set_option("gemm_kernel", k[0])
-            ops.set_option("gemm_var", k[1])
-            fn = (lambda: ops.linear(x, lin, g1=gate, res=xs, out_f32=True, out=xs)) if res else (lambda: ops.linear(x, lin, out=out))
+            if k[0] == "blas":
+                if res:
+                    times[k].append(float("nan"))
+                    continue
+                wt = lin.w[:N, :K].t()
+                fn = lambda: torch.matmul(x, wt, out=out)
+            else:
+                ops.set_option("gemm_kernel", k[0])
+                ops.set_option("gemm_var", k[1])
+                fn = (lambda: ops.linear(x, lin, g1=gate, res=xs, out_f32=True, out=xs)) if res else (lambda: ops.linear(x, lin, out=out))
             fn()
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
