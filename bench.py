@@ -153,6 +153,9 @@ def dry_run(args):
 
 
 def main():
+    # dmabuf IPC only on this driver: RCCL's first collective fails without it.  Set here too (not only in self_launch): the driver
+    # launches the ranks itself (`python -m torch.distributed.run ... bench.py`), and it must be in place before the HSA runtime starts.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -166,7 +169,9 @@ def main():
 
     # a multi-rank run that stops making progress (a collective one rank never issues) would otherwise sit silent until the caller's
     # own limit: dump every thread's Python stack and exit non-zero instead.  FW_BENCH_WATCHDOG_S = seconds, 0 = off.
-    wd = float(os.environ.get("FW_BENCH_WATCHDOG_S", "0" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "2700"))
+    # Default at N > 1: 900 s -- well inside the driver's own limit (1800 s in BENCH_r03.json), so a hang ends with stacks in the log
+    # instead of a silent kill; a healthy 8-rank run (engine build + golden check + 25 steps of < 1 s) needs a fraction of it.
+    wd = float(os.environ.get("FW_BENCH_WATCHDOG_S", "0" if int(os.environ.get("WORLD_SIZE", "1")) == 1 else "900"))
     if wd > 0:
         import faulthandler
         faulthandler.dump_traceback_later(wd, exit=True)
@@ -186,6 +191,21 @@ def main():
     torch.cuda.set_device(local)
     ops = HipOps(dev)
     stats = parallel.enable_comm_stats() if world > 1 else None
+
+    # N > 1: before anything is measured, the small golden case (the REAL reference's output, tests/golden/) goes through THIS
+    # rank's shard of the topology -- every exchange the measured forward makes.  A rank set that is off the golden prints no
+    # throughput (value = null, exit code 3).  FW_BENCH_GOLDEN_CHECK=0 skips it.
+    golden = None
+    if world > 1 and os.environ.get("FW_BENCH_GOLDEN_CHECK", "1") != "0":
+        golden = parallel.golden_self_check(topo, ops)
+        if not golden["ok"]:
+            if rank == 0:
+                print(json.dumps({"metric": "denoise-steps/sec (81x480x832 latents, 14B WanDiT + IRG + VGGT branch)", "value": None,
+                                  "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                  "error": "multi-rank forward is off the reference golden: no throughput reported",
+                                  "golden_check": golden, "config": {"workload": "refused", "parallelism": topo.describe()}}), flush=True)
+            torch.distributed.destroy_process_group()
+            raise SystemExit(3)
 
     wan22 = args.model == "wan22"
     cfg = fwc.wan22_a14b() if wan22 else fwc.wan21_14b()
@@ -268,6 +288,7 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(latents.float()).all(), "non-finite latents"
 
+    fp8_attn = bool(getattr(eng, "fp8_attention", False))        # what the engine that was BUILT runs, not what was asked for
     Li = cfg.clip_tokens if cfg.has_image_input else 0
     f_fwd = forward_flops(cfg, L, L2, F, P, 512, Li)
     step_flops = 2.0 * f_fwd
@@ -329,14 +350,14 @@ def main():
         "value": value, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": ("fp8_e4m3 linears (fp32 accumulate), " + ("fp8_e4m3 DiT self-attention (fp32 scores / softmax / accumulate; parity unpinned)"
-                                                          if args.fp8_attention else "bf16 attention"))
+                                                          if fp8_attn else "bf16 attention"))
                  if args.precision == "fp8" else "bf16", "data": "synthetic",
         "config": {"workload": workload, "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,
                    "parallelism": topo.describe(), "step_invariant_cache": bool(args.cache_invariants),
                    "cfg_merged_in_one_pass": bool(args.merge_cfg and world == 1),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
-        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_pp_kernel" if args.fp8_attention else "attention_sp_kernel<128, 65>") + " (DiT self-attention, one launch per block"
+        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_pp_kernel" if fp8_attn else "attention_sp_kernel<128, 65>") + " (DiT self-attention, one launch per block"
                                + ("" if n_groups == 1 else f", in {n_groups} head groups under the sequence shard")
                                + ("" if topo.tp is None else f", {cfg.num_heads // sp} of {cfg.num_heads} heads per tensor-parallel rank") + ")",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
@@ -372,6 +393,14 @@ def main():
                                     "timestep / (cfg_scale, dsigma) / latents fed through device buffers; `value` stays the eager number"}
         del gstep
     if comm is not None:
+        # which exchange pattern ran (the grouped q|k|v exchange falls back to one exchange per attention on a rank set where its
+        # probe does not complete), what the reduced partial sums of the TP partition are rounded to, and what the bytes cost here
+        comm["exchange_groups"] = None if shard is None else shard.exchange_probe
+        comm["tp_reduce_dtype"] = None if topo.tp is None else str(topo.tp.reduce_dtype).replace("torch.", "")
+        try:
+            comm["microbench"] = parallel.comm_microbench(topo, dev, rows=L // sp * sp if topo.tp is None else L)
+        except Exception as e:                       # a measurement aid must never take the line down
+            comm["microbench"] = {"error": repr(e)[:200]}
         comm["note"] = ("per GPU (this is rank 0); exposed = time the compute stream was blocked inside Pending.wait(); "
                         "issue_to_done = issue -> completion windows summed (upper bound on the exchanges' own duration)")
         out["comm"] = comm
@@ -388,6 +417,9 @@ def main():
         except OSError:
             pass
         out["cpu_baseline"] = cb
+    out["watchdog_s"] = wd
+    if golden is not None:
+        out["golden_check"] = golden
     if rank == 0:
         print(json.dumps(out), flush=True)
     if wd > 0:

@@ -20,7 +20,7 @@ static void opt_init() {
     if (g_opt_init) return;
     g_opt_init = true;
     const char* names[FW_OPT_COUNT] = {"FW_GEMM_TILE", "FW_GEMM_KERNEL", "FW_GEMM_VAR", "FW_ATTN_VAR"};
-    const int defaults[FW_OPT_COUNT] = {0, 4, 0, 192};
+    const int defaults[FW_OPT_COUNT] = {0, 9, 0, 192};
     for (int i = 0; i < FW_OPT_COUNT; ++i) {
         const char* e = getenv(names[i]);
         g_opt[i] = e ? atoi(e) : defaults[i];

@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     } else if (UNR) {
         int t = 0;
 #pragma unroll 1
+        static_assert(ARING == 4, "the body below is unrolled by hand over ring slots 0..3");
         for (; t + ARING <= nt - 1; t += ARING) {       // t is a multiple of the ring depth here: slots 0, 1, 2, 3
             tile(t, std::integral_constant<int, 0>{}, F_{});
             tile(t + 1, std::integral_constant<int, 1>{}, F_{});

@@ -6,9 +6,9 @@ out="${here}/../libfw_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result)
 objs=()
-for f in gemm.hip attention.hip elementwise.hip heads.hip fp8.hip gemm_fp8.hip attention_fp8.hip; do
+for f in gemm.hip gemm_pp.hip attention.hip elementwise.hip heads.hip fp8.hip gemm_fp8.hip attention_fp8.hip; do
   o="${here}/${f%.hip}.o"
-  if [ ! -f "$o" ] || [ "${here}/$f" -nt "$o" ] || [ "${here}/fw_common.h" -nt "$o" ] || [ "${here}/../../include/fw_mi355x.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "${here}/$f" -nt "$o" ] || [ "${here}/fw_common.h" -nt "$o" ] || [ "${here}/gemm_common.h" -nt "$o" ] || [ "${here}/../../include/fw_mi355x.h" -nt "$o" ]; then
     if [ "$f" = "fp8.hip" ]; then   # IEEE division for the fp8 quantiser: no -ffast-math
       "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "${here}/$f" -o "$o" &
     elif [ "$f" = "attention.hip" ]; then

@@ -23,7 +23,7 @@ ROPE = {None: 0, "none": 0, "interleaved": 1, "half2d": 2}
 SYMBOLS = [
     "fw_abi_version", "fw_last_error", "fw_gemm_bf16", "fw_attention_bf16", "fw_attention_workspace_bytes", "fw_v_transpose", "fw_layernorm_mod",
     "fw_qk_prep", "fw_gemv_f32", "fw_sinusoid", "fw_patchify", "fw_unpatchify", "fw_assemble_tokens",
-    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_debug_gemm_timestamps", "fw_control_patchify", "fw_im2col3x3",
+    "fw_cast_f32_bf16", "fw_set_option", "fw_debug_attention_timestamps", "fw_debug_gemm_timestamps", "fw_debug_gemm_pp_timestamps", "fw_control_patchify", "fw_im2col3x3",
     "fw_im2col", "fw_conv_gemm_bf16", "fw_v_transpose_fp8", "fw_attention_fp8", "fw_resize_bilinear", "fw_chan_rmsnorm_silu", "fw_depth_to_space", "fw_add_table", "fw_unfold_time2",
     "fw_add_act", "fw_adaln_rows", "fw_head_activation",
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
@@ -65,6 +65,7 @@ def load_library(path: str = LIB_PATH):
         "fw_set_option": [i32, i32],
         "fw_debug_attention_timestamps": [vp, i32],
         "fw_debug_gemm_timestamps": [vp, i32],
+        "fw_debug_gemm_pp_timestamps": [vp, i32],
         "fw_control_patchify": [vp, i32, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

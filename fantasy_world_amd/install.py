@@ -59,23 +59,46 @@ def heads_config_from_model(vggt):
         point_out=pts.scratch.output_conv2[2].out_channels)
 
 
+class _PackedParams:
+    """The getter the engine packs from: name -> live Parameter, RECORDING every name it hands out.  The record is what
+    `release_reference_weights` releases (exactly the tensors that were packed -- not everything under a prefix) and what
+    _WeightWatch watches.  A name asked for AFTER its storage was released fails with a clear message instead of packing a 0-element
+    tensor."""
+
+    def __init__(self, params):
+        self.params = params
+        self.fetched = []
+        self._seen = set()
+        self.released = set()
+
+    def __call__(self, name):
+        if name in self.released:
+            raise RuntimeError(f"{name}: the reference's copy of this parameter was released by "
+                               "install(..., release_reference_weights=True); build / load the model again")
+        if name not in self._seen:
+            self._seen.add(name)
+            self.fetched.append(name)
+        return self.params[name]
+
+
 class _WeightWatch:
-    """Cheap evidence that the live module tree still holds the tensors that were packed: a spread of ~24 parameters is
-    remembered BY MODULE AND NAME at install time and re-read per call (no walk over the module tree): load_state_dict, a LoRA
-    merge done with in-place tensor ops, `.to()` / `.half()` or re-assigned Parameters change the storage address or the in-place
-    version counter of at least the sampled tensors.
+    """Evidence that the live module tree still holds the tensors that were packed: EVERY packed parameter is remembered BY MODULE
+    AND NAME at install time and its (storage address, in-place version) re-read per call -- ~1 700 slots, well under a millisecond
+    against a forward of seconds, no walk over the module tree: load_state_dict, a LoRA merge done with in-place tensor ops, a partial
+    load that touches a single block, `.to()` / `.half()` or re-assigned Parameters all change at least one watched slot.
     NOT detected: edits that go through `.data` (`p.data += delta`, `p.data.add_(...)`) -- autograd's version counter does not
     see them and the address stays; call `install(model)` again after such a merge, or `verify()` (one device sync: compares
-    content checksums of the sampled tensors with the ones taken at install time)."""
+    content checksums of a spread of the watched tensors with the ones taken at install time)."""
 
-    def __init__(self, model, every=24):
-        named = sorted(model.named_parameters(), key=lambda kv: kv[0])
-        pick = named[:: max(1, len(named) // every)]
+    def __init__(self, model, names=None, checksum_every=24):
         mods = dict(model.named_modules())
+        if names is None:
+            names = [k for k, _ in model.named_parameters()]
         self.slots = []
-        for name, _ in pick:
+        for name in sorted(names):
             owner, _, leaf = name.rpartition(".")
             self.slots.append((name, mods[owner], leaf))
+        self.sum_slots = self.slots[:: max(1, len(self.slots) // checksum_every)]
         self.signature = self._read()
         self.checksums = self._sums()
 
@@ -83,19 +106,23 @@ class _WeightWatch:
         out = []
         for name, mod, leaf in self.slots:
             p = mod._parameters.get(leaf)
-            out.append((name, None, None) if p is None else (name, p.data_ptr(), p._version))
-        return tuple(out)
+            out.append((None, None) if p is None else (p.data_ptr(), p._version))
+        return out
 
     def _sums(self):
-        vals = [mod._parameters[leaf].detach().reshape(-1)[:4096].double().sum() for _, mod, leaf in self.slots
-                if mod._parameters.get(leaf) is not None]
+        vals = [mod._parameters[leaf].detach().reshape(-1)[:4096].double().sum() for _, mod, leaf in self.sum_slots
+                if mod._parameters.get(leaf) is not None and mod._parameters[leaf].numel()]
         return torch.stack(vals).cpu() if vals else torch.zeros(0)
 
     def unchanged(self):
         return self._read() == self.signature
 
+    def changed_names(self, limit=4):
+        now = self._read()
+        return [self.slots[i][0] for i in range(len(now)) if now[i] != self.signature[i]][:limit]
+
     def verify(self):
-        """Content check of the sampled tensors (syncs the device once): also catches `.data` edits."""
+        """Content check of a spread of the watched tensors (syncs the device once): also catches `.data` edits."""
         return self.unchanged() and torch.equal(self._sums(), self.checksums)
 
 
@@ -190,6 +217,9 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     install() after checkpoint loading / LoRA merging / .to(dtype).  A later change of the live parameters is detected at the
     next joint_forward (RuntimeError: install again) instead of being silently ignored; installing again drops the previous
     engine and its caches first."""
+    if getattr(model, "_fw_released_weights", 0):
+        raise RuntimeError("this model's reference weights were released by install(..., release_reference_weights=True): there is "
+                           "nothing left to pack from -- build / load the model again, then install()")
     if hasattr(model, "_fw_engine"):
         model._fw_engine.invariants.clear()
         uninstall(model)
@@ -203,38 +233,39 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     pairing = CfgPairing(topo) if topo is not None and topo.cfg_groups == 2 else None
     if pairing is None and merge_cfg and shard is None and (topo is None or topo.world == 1):
         pairing = CfgPairing(None)
-    params = dict(model.named_parameters())
+    get = _PackedParams(dict(model.named_parameters()))
     if topo is not None and topo.tp is not None:          # north_star's head / FFN-column partition (tensor_parallel.py)
         from .tensor_parallel import TPFusionEngine
-        engine = TPFusionEngine(cfg, params.__getitem__, ops, topo.tp, heads_cfg=heads_config_from_model(model.vggt),
+        engine = TPFusionEngine(cfg, get, ops, topo.tp, heads_cfg=heads_config_from_model(model.vggt),
                                 cache_step_invariants=cache_step_invariants, precision=precision)
     else:
-        engine = FusionEngine(cfg, params.__getitem__, ops, heads_cfg=heads_config_from_model(model.vggt),
+        engine = FusionEngine(cfg, get, ops, heads_cfg=heads_config_from_model(model.vggt),
                               cache_step_invariants=cache_step_invariants, precision=precision, shard=shard)
-    released = []
     if release_reference_weights:
         if engine.heads_cfg is not None:
             engine.geometry_heads()                              # pack now: their source tensors are about to go
-        keep = ("camera_condition.pose_encoder.",)                # packed lazily by get_pose_fea
-        if engine.heads_cfg is None:                             # a head is disabled: the reference's own head modules stay in use
-            keep += ("vggt.camera_head.", "vggt.depth_head.", "vggt.point_head.", "vggt.track_head.")
-        packed_prefixes = ("pipe.dit.", "IRGBlock.", "vggt.")
+        # EXACTLY what the engine (and its geometry heads) fetched: the track head, aggregator blocks beyond the IRG depth, the
+        # aggregator's own patch embedding, the pose encoder (packed lazily by get_pose_fea) and anything a later reference version
+        # adds under pipe.dit / vggt keep their storage and stay usable
         with torch.no_grad():
-            for name, p in params.items():
-                if name.startswith(packed_prefixes) and not name.startswith(keep):
-                    p.data = torch.empty(0, dtype=p.dtype, device=p.device)
-                    released.append(name)
-        model._fw_released_weights = len(released)
-    watch = _WeightWatch(model)
+            for name in get.fetched:
+                p = get.params[name]
+                p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+                get.released.add(name)
+        model._fw_released_weights = len(get.released)
+    watch = _WeightWatch(model, names=get.fetched)
     engine.weight_watch = watch
-    del params
+    import weakref
+    model_ref = weakref.ref(model)
 
     def joint_forward(self, x, timestep, context, clip_feature=None, y=None, use_gradient_checkpointing=True,
                       camera_token=None, plucker_fea=None, plucker_context_lens=None, uncond=False,
                       return_prediction=False, control_camera_latents_input=None, **kwargs):
         if not watch.unchanged():
             raise RuntimeError("the model's parameters changed after fantasy_world_amd.install() (load_state_dict, LoRA merge, "
-                               ".to()): the engine runs on a packed snapshot -- call install(model) again")
+                               f".to(); e.g. {watch.changed_names()}): the engine runs on a packed snapshot -- "
+                               + ("build / load the model again (its reference weights were released)"
+                                  if getattr(self, "_fw_released_weights", 0) else "call install(model) again"))
         def forward(ctx, want_prediction):
             return engine.joint_forward(x, timestep, ctx, clip_feature=clip_feature, y=y,
                                         plucker_fea=plucker_fea, plucker_context_lens=plucker_context_lens,
@@ -271,8 +302,15 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                              return_prediction=return_prediction,
                              control_camera_latents_input=control_camera_latents_input)
 
-    model._fw_reference_joint_forward = model.joint_forward
-    model.joint_forward = types.MethodType(joint_forward22 if cfg.control_adapter else joint_forward, model)
+    # An instance attribute holding a BOUND method would tie model -> method -> model into a reference cycle (36 GB of packed weights
+    # waiting for the cyclic collector after `del model`): the rebound entry reaches the model through a weak reference instead.
+    impl = joint_forward22 if cfg.control_adapter else joint_forward
+
+    def rebound(*args, **kwargs):
+        return impl(model_ref(), *args, **kwargs)
+    rebound.__name__, rebound.__doc__ = "joint_forward", impl.__doc__
+    model._fw_reference_joint_forward = model.__dict__.get("joint_forward")      # None: the class's own method
+    model.joint_forward = rebound
     model._fw_engine = engine
     engine.cfg_pairing = pairing
 
@@ -287,11 +325,12 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                 return None
             if "enc" not in state:
                 from .pose_encoder import PoseEncoder
-                state["enc"] = PoseEncoder(dict(model.named_parameters()).__getitem__, ops)
+                state["enc"] = PoseEncoder(dict(model_ref().named_parameters()).__getitem__, ops)
             return state["enc"].encode(plucker)
 
-        cam._fw_reference_get_pose_fea = cam.get_pose_fea
-        cam.get_pose_fea = types.MethodType(get_pose_fea, cam)
+        cam_ref = weakref.ref(cam)
+        cam._fw_reference_get_pose_fea = cam.__dict__.get("get_pose_fea")
+        cam.get_pose_fea = lambda plucker: get_pose_fea(cam_ref(), plucker)
     return engine
 
 
@@ -326,15 +365,19 @@ def uninstall(model):
     if getattr(model, "_fw_released_weights", 0):
         raise RuntimeError("install(..., release_reference_weights=True) released the reference's own copy of the weights: the "
                            "reference forward cannot be restored -- build / load the model again")
-    if hasattr(model, "_fw_reference_joint_forward"):
-        model.joint_forward = model._fw_reference_joint_forward
-        del model._fw_reference_joint_forward
+    def restore(obj, attr, saved):
+        prev = obj.__dict__.pop(saved)
+        if prev is None:
+            obj.__dict__.pop(attr, None)          # back to the class's own method
+        else:
+            setattr(obj, attr, prev)
+    if "_fw_reference_joint_forward" in model.__dict__:
+        restore(model, "joint_forward", "_fw_reference_joint_forward")
         model._fw_engine.invariants.clear()
         del model._fw_engine
     cam = getattr(model, "camera_condition", None)
-    if cam is not None and hasattr(cam, "_fw_reference_get_pose_fea"):
-        cam.get_pose_fea = cam._fw_reference_get_pose_fea
-        del cam._fw_reference_get_pose_fea
+    if cam is not None and "_fw_reference_get_pose_fea" in cam.__dict__:
+        restore(cam, "get_pose_fea", "_fw_reference_get_pose_fea")
 
 
 def install_flash_attention(modules, ops=None, device=None, name="flash_attention"):

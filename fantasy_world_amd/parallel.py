@@ -25,7 +25,14 @@ Two levels, chosen from what the path offers and what the xGMI mesh (7 point-to-
 Layout: DiT tokens are split into contiguous row ranges (L = 32760 = 4 * 8190), VGGT tokens by whole frames (frame attention
 is per frame; 21 frames over 4 ranks = 6,5,5,5).
 """
+import os
+import time
 from typing import List
+
+# The host driver of the MI355X boxes only supports dmabuf IPC: without this RCCL (and any CUDA-tensor sharing across processes) fails
+# with `hipIpcGetMemHandle: invalid argument` at the first collective.  Set before the HSA runtime starts, however the ranks were
+# launched (the driver's own `python -m torch.distributed.run ... bench.py`, a user's torchrun around the reference script, ...).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
@@ -132,9 +139,58 @@ class Ready(Pending):
 
 
 class SequenceShard:
-    def __init__(self, rank: int, world: int, group=None):
+    def __init__(self, rank: int, world: int, group=None, probe_group=None):
         self.rank, self.world, self.group = rank, world, group
+        self.probe_group = probe_group        # a second communicator over the same ranks, used ONLY by probe_grouped_exchange
         self._grid = None
+        self.exchange_probe = None            # {"requested", "ran", "ok", "seconds"} once negotiated (bench.py `comm` block)
+
+    def negotiate_exchange_groups(self, requested, device, timeout_s=None):
+        """How many head groups a DiT self-attention exchange may be cut into (FusionEngine.exchange_groups).  More than one group
+        means a SECOND all-to-all is issued while the first is still in flight (and the inverse exchange of group g while group
+        g+1 travels).  RCCL runs a communicator's collectives in issue order on its own stream, where that is fine -- but it has
+        never run on more than one rank here, and gloo's device staging stalled on exactly this pattern
+        (profiles/r03/dryrun_ranks_small.txt).  So the pattern is tried once, on small tensors, on the PROBE communicator: if it does
+        not complete within `timeout_s` ($FW_SP_PROBE_TIMEOUT_S, default 20) on every rank, the engine falls back to one exchange
+        per attention (every rank takes the same decision: MIN over the group) and the probe communicator is never used again (the
+        stuck collectives stay on it, away from the communicator the forward uses).  The outcome is kept in `exchange_probe`."""
+        if self.exchange_probe is not None and self.exchange_probe["requested"] == requested:
+            return self.exchange_probe["ran"]
+        ran, ok, secs = requested, True, 0.0
+        if requested > 1 and self.world > 1:
+            if timeout_s is None:
+                timeout_s = float(os.environ.get("FW_SP_PROBE_TIMEOUT_S", "20"))
+            t0 = time.monotonic()
+            ok = self._probe_grouped_exchange(device, timeout_s)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)      # plain blocking collective on the forward's communicator
+            ok = bool(int(flag.item()))
+            secs = time.monotonic() - t0
+            if not ok:
+                ran = 1
+        self.exchange_probe = {"requested": int(requested), "ran": int(ran), "ok": bool(ok), "seconds": round(secs, 3)}
+        return ran
+
+    def _probe_grouped_exchange(self, device, timeout_s):
+        n = self.world
+        pr = SequenceShard(self.rank, n, self.probe_group if self.probe_group is not None else self.group)
+        rows, c = 8, 4
+        counts = [rows] * n
+        qkv = (torch.arange(rows * 3 * n * 2 * c, dtype=torch.float32, device=device).view(rows, 3 * n * 2 * c) + 1000.0 * self.rank)
+        pend = [pr.rows_to_heads_async(qkv, 3, counts, (0, c)), pr.rows_to_heads_async(qkv, 3, counts, (c, 2 * c))]
+        back = pr.heads_to_rows_async(torch.full((rows * n, c), float(self.rank), device=device), counts)
+        self._probe_keepalive = (pend, back, qkv)          # a stuck collective must not be destroyed under the backend
+        deadline = time.monotonic() + timeout_s
+        for w in [p._work for p in pend] + [back._work]:
+            while not w.is_completed():
+                if time.monotonic() > deadline:
+                    return False
+                time.sleep(0.002)
+        # completed: the data must also be what the exchange promises (rank r's rows carry 1000 r)
+        got = pend[1].wait()
+        want = torch.cat([qkv.view(rows, 3, n, 2 * c)[:, :, self.rank, c:2 * c] - 1000.0 * self.rank + 1000.0 * r for r in range(n)], dim=0)
+        self._probe_keepalive = None
+        return bool(torch.equal(got, want))
 
     # ---- per-grid bookkeeping -----------------------------------------------------------------------------------
     def _setup(self, F, hw, n_special):
@@ -310,27 +366,41 @@ def make_topology(rank, world, local=0, cfg_parallel=True, mode="sp", reduce_dty
         if mode == "tp":
             from .tensor_parallel import TensorShard
             kw = {} if reduce_dtype is None else dict(reduce_dtype=reduce_dtype)
-            return dict(tp=TensorShard(r, n, group, **kw))
-        return dict(shard=SequenceShard(r, n, group))
+            return dict(tp=TensorShard(r, n, group[0], **kw))
+        return dict(shard=SequenceShard(r, n, group[0], probe_group=group[1]))
+
+    def groups_for(ranks):
+        # (the forward's communicator, the probe communicator of SequenceShard.negotiate_exchange_groups); new_group is collective
+        # over the WORLD: every rank creates every group, in the same order
+        main = dist.new_group(ranks)
+        probe = dist.new_group(ranks) if (mode == "sp" and len(ranks) > 1) else None
+        return main, probe
 
     if cfg_parallel and world % 2 == 0:
         n = world // 2
-        groups = [dist.new_group(list(range(g * n, (g + 1) * n))) for g in range(2)]
+        groups = [groups_for(list(range(g * n, (g + 1) * n))) for g in range(2)]
         cfg_rank, sp_rank = rank // n, rank % n
         return Topology(rank, world, local, 2, cfg_rank, **inner(sp_rank, n, groups[cfg_rank]))
-    return Topology(rank, world, local, 1, 0, **inner(rank, world, None))
+    return Topology(rank, world, local, 1, 0, **inner(rank, world, groups_for(list(range(world)))))
 
 
 def init_topology(backend=None, cfg_parallel=True, mode=None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) -> Topology.
     mode: "sp" | "tp"; default from $FW_PARALLEL, else "sp"."""
-    import os
     mode = mode or os.environ.get("FW_PARALLEL", "sp")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
         return Topology(local=local)
+    # FW_TP_REDUCE_DTYPE: dtype of the all-reduced partial sums of the tensor-parallel partition.  Default fp32, decided from the
+    # parity data (tests/golden/parity_bounds_gpu.json `tp/world4/*`): with fp32 partial sums the sharded forward sits at the
+    # unsharded one's distance from the fp32 golden (2.68e-3), with bf16 partial sums at 3.2e-3 -- +20 % error for half the bytes.
+    # What the bytes cost is measured by bench.py at N > 1 (`comm.microbench`: the same [rows, 5120] all-reduce in both dtypes),
+    # so the first hardware run records the price of this default next to it; bf16 stays one environment variable away.
+    reduce_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(os.environ.get("FW_TP_REDUCE_DTYPE", "fp32"))
+    if reduce_dtype is None:
+        raise ValueError("FW_TP_REDUCE_DTYPE must be fp32 or bf16")
     if not dist.is_initialized():
         if backend is None:
             # "nccl" IS RCCL on ROCm.  FW_DIST_BACKEND=gloo: debugging aid for the CFG-parallel path only (several ranks sharing
@@ -339,7 +409,6 @@ def init_topology(backend=None, cfg_parallel=True, mode=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    reduce_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(os.environ.get("FW_TP_REDUCE_DTYPE", ""))
     return make_topology(rank, world, local, cfg_parallel, mode=mode, reduce_dtype=reduce_dtype)
 
 
@@ -347,13 +416,91 @@ def make_engine(cfg, get, ops, topo=None, **kw):
     """The engine for this rank's place in `topo`: FusionEngine (single GPU / sequence shard) or TPFusionEngine."""
     if topo is not None and topo.tp is not None:
         from .tensor_parallel import TPFusionEngine
-        kw.pop("fp8_attention", None)
+        if kw.pop("fp8_attention", False):
+            raise ValueError("fp8_attention is not available under the tensor-parallel partition (FW_PARALLEL=tp)")
         return TPFusionEngine(cfg, get, ops, topo.tp, **kw)
     from .engine import FusionEngine
-    return FusionEngine(cfg, get, ops, shard=None if topo is None else topo.shard, **kw)
+    eng = FusionEngine(cfg, get, ops, shard=None if topo is None else topo.shard, **kw)
+    if eng.shard is not None and eng.shard.world > 1:
+        # the grouped q|k|v exchange is tried once on a side communicator; a rank set on which it does not complete runs one
+        # exchange per attention instead (SequenceShard.negotiate_exchange_groups)
+        dev = getattr(ops, "device", None) or "cpu"
+        eng.exchange_groups = eng.shard.negotiate_exchange_groups(eng.exchange_groups, dev)
+    return eng
 
 
 def init_from_env(backend=None):
     """Back-compat: (shard | None, rank, world, local_rank) with ONE sequence-sharded group (no CFG split)."""
     topo = init_topology(backend, cfg_parallel=False)
     return topo.shard, topo.rank, topo.world, topo.local
+
+
+def golden_self_check(topo, ops, case="wan21_cfg1_l2_f9_64x64", tol=8e-3, golden_dir=None):
+    """First-run safety of a multi-rank measurement (bench.py at N > 1): the small golden case -- the REAL reference's fp32
+    joint_forward on BASELINE configs[0] (2-block model, latents [1,16,9,64,64]; tests/golden/, generated by oracle/make_golden.py
+    from the imported reference) -- through THIS rank's place in `topo` (its sequence shard / tensor-parallel shard, every exchange
+    the measured forward makes).  Returns {"case", "tol", "rel_l2" (MAX over ranks), "ok"}; a rank set that is off the golden must
+    not print a throughput.  9 latent frames shard over up to 8 ranks."""
+    import torch.distributed as dist
+    from . import config as fwc, synth
+    gdir = golden_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    g = torch.load(os.path.join(gdir, case + ".pt"), map_location="cpu", weights_only=False)
+    meta = g["meta"]
+    cfg = (fwc.plumbing22 if meta.get("flavour") == "wan22" else fwc.plumbing)(**meta["cfg"])
+    f, h2, w2 = meta["grid"]
+    W = synth.LazyWeights(synth.weight_spec(cfg), seed=meta["seed_weights"])          # CPU generators: the golden's own weights
+    dev = getattr(ops, "device", None) or "cpu"
+    eng = make_engine(cfg, W.__getitem__, ops, topo)
+    ins = synth.make_inputs(cfg, f, h2, w2, seed=meta["seed_inputs"], timestep=meta["timestep"], text_len=meta["text_len"], device=dev)
+    kw = dict(y=ins["y"])
+    if cfg.control_adapter:
+        kw["control_camera_latents_input"] = ins["control_camera_latents_input"]
+    else:
+        kw.update(clip_feature=ins["clip_feature"], plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"])
+    out, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], uncond=meta["uncond"], **kw)
+    want = g["noise_pred"].to(out.device).double()
+    err = ((out.double() - want).norm() / want.norm()).reshape(1).to(torch.float64)
+    if not torch.isfinite(err).all():
+        err = torch.full_like(err, float("inf"))
+    if topo is not None and topo.world > 1:
+        dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    e = float(err.item())
+    del eng
+    return {"case": case, "tol": tol, "rel_l2_max_over_ranks": e, "ok": bool(e < tol)}
+
+
+def comm_microbench(topo, device, rows, width=5120, iters=3):
+    """What the bytes cost on THIS machine's links, measured once beside a multi-rank bench line (`comm.microbench`): the
+    [rows, width] all-reduce of the tensor-parallel partition in bf16 and in fp32 (the FW_TP_REDUCE_DTYPE decision), and the q|k|v
+    head all-to-all of the sequence shard, on the rank group that shares one forward.  ms per call, MAX over the group's ranks."""
+    import torch.distributed as dist
+    group = topo.tp.group if topo.tp is not None else (topo.shard.group if topo.shard is not None else None)
+    n = topo.group_world
+    if n <= 1:
+        return None
+    cuda = torch.device(device).type == "cuda"
+
+    def timed(fn):
+        fn()
+        if cuda:
+            torch.cuda.synchronize()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        if cuda:
+            torch.cuda.synchronize()
+        dt = torch.tensor([1e3 * (time.perf_counter() - t0) / iters], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=group)
+        return float(dt.item())
+    out = {"rows": int(rows), "width": int(width), "ranks": int(n)}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        t = torch.ones(rows, width, dtype=dt, device=device)
+        out[f"all_reduce_{name}_ms"] = timed(lambda: dist.all_reduce(t, group=group))
+        out[f"all_reduce_{name}_bytes"] = t.numel() * t.element_size()
+    r = rows // n
+    src = torch.ones(n * r, 3 * width // n, dtype=torch.bfloat16, device=device)
+    dst = torch.empty_like(src)
+    out["all_to_all_qkv_bf16_ms"] = timed(lambda: dist.all_to_all_single(dst, src, group=group))
+    out["all_to_all_qkv_bf16_bytes"] = src.numel() * 2
+    return out

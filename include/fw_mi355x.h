@@ -60,9 +60,11 @@ int fw_abi_version(void);
  * Each slot is initialised once from the environment variable of the same name.
  */
 #define FW_OPT_GEMM_TILE   0   /* FW_GEMM_TILE: 0 = auto, 128 / 256 = force the tile family */
-#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 4 (default) = 8-wave ping-pong kernel;
-                                  5 = four-wave 128x128-wave-tile kernel for every big GEMM (independent implementation, A/B) */
-#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: 0 (default); bit 1 = TIMING build of the ping-pong kernel (phase + tile stamps),
+#define FW_OPT_GEMM_KERNEL 1   /* FW_GEMM_KERNEL: 9 (default) = 8-wave TWO-slot ping-pong kernel (round 4, gemm_pp.hip; the implicit-GEMM
+                                  convolutions and operands with a row stride >= 2^21 elements stay on 4); 4 = 8-wave four-slot
+                                  ping-pong kernel (the default of rounds 2-3); 5 = four-wave 128x128-wave-tile kernel (independent
+                                  implementation, A/B).  All three keep the same k order per output element: bit-identical results */
+#define FW_OPT_GEMM_VAR    2   /* FW_GEMM_VAR: 0 (default); bit 1 = TIMING build of the ping-pong kernel (4: phase + tile stamps; 9: phase stamps),
                                   bit 2 = tile stamps only (tools/gemm_timeline.py); value >> 4 (if non-zero) = M-tiles per group of
                                   the tile order (default 4 for outputs >= 20 column tiles wide, else 8; tools/gemm_ab.py) */
 #define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
@@ -79,6 +81,7 @@ int fw_set_option(int opt, int value);
 /* Measurement hook: shader-clock timestamps [wave 0..7][8] of work-group 0 at KV tile 100, written by the TIMING build of the
  * ping-pong attention kernel (FW_ATTN_VAR = 66); synchronous copy to host memory. */
 int fw_debug_gemm_timestamps(unsigned long long* host_out, int n);   /* same, GEMM ping-pong kernel (FW_GEMM_KERNEL=4, var bit 1) */
+int fw_debug_gemm_pp_timestamps(unsigned long long* host_out, int n);   /* same, two-slot GEMM kernel (FW_GEMM_KERNEL=9, var bit 1): [group 0..1][slab 16..19][8] */
 int fw_debug_attention_timestamps(unsigned long long* host_out, int n);
 
 /* Human-readable description of the last negative error on this thread (never NULL). */

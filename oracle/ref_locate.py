@@ -23,6 +23,20 @@ def _ok(root):
     return bool(root) and os.path.isdir(os.path.join(root, "FantasyWorld", "fusion"))
 
 
+def _trusted(root, tag):
+    """An extraction of bundle `tag` that this user made: owned by us, not writable by group / others, complete."""
+    if not _ok(root):
+        return False
+    st = os.stat(root)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        return False
+    try:
+        with open(os.path.join(root, ".fw_bundle")) as f:
+            return f.read().strip() == tag
+    except OSError:
+        return False
+
+
 def reference_root():
     """-> directory holding `FantasyWorld/` (importable as a package root), or None."""
     global _cached
@@ -35,16 +49,26 @@ def reference_root():
     if os.path.isfile(BUNDLE):
         with open(BUNDLE, "rb") as f:
             tag = hashlib.sha1(f.read()).hexdigest()[:12]
-        dst = os.path.join(tempfile.gettempdir(), f"fw_reference_{tag}")
-        if not _ok(dst):
-            tmp = tempfile.mkdtemp(prefix="fw_reference_x_")
+        # Extracted into a PER-USER directory of mode 0700 (never a predictable path in the shared temp dir that another user of the
+        # machine could pre-plant: the test process imports what it finds there), member paths checked by tarfile's "data" filter,
+        # and a directory found there is only trusted when this user owns it, nobody else can write it, and it carries the marker
+        # written after a COMPLETE extraction of THIS bundle (its hash).
+        base = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "fw_reference")
+        dst = os.path.join(base, tag)
+        if not _trusted(dst, tag):
+            os.makedirs(base, mode=0o700, exist_ok=True)
+            os.chmod(base, 0o700)
+            tmp = tempfile.mkdtemp(prefix=f"{tag}_x_", dir=base)
             with tarfile.open(BUNDLE, "r:gz") as tar:
-                tar.extractall(tmp)
+                tar.extractall(tmp, filter="data")
+            with open(os.path.join(tmp, ".fw_bundle"), "w") as f:
+                f.write(tag)
             try:
                 os.rename(tmp, dst)
-            except OSError:                 # another process won the race
-                pass
-        if _ok(dst):
+            except OSError:                 # another process of this user won the race (or a stale directory is in the way)
+                if not _trusted(dst, tag):
+                    dst = tmp               # use the private extraction itself
+        if _trusted(dst, tag):
             _cached = dst
             return dst
     _cached = ""

@@ -104,17 +104,18 @@ def test_gemm_big_tile_kernels_agree(ops, ref, M, N, K, parity):
     xd = bf(x).cuda()
     try:
         outs = {}
-        for kern in (4, 5):
+        for kern in (4, 5, 9):
             ops.set_option("gemm_kernel", kern)
             outs[kern] = ops.linear(xd, lin, out_f32=True)
         torch.cuda.synchronize()
     finally:
-        ops.set_option("gemm_kernel", 4)
-    parity.check(f"op/gemm_big_f32out/{M}x{N}x{K}", rel_l2(outs[4], want), 1e-3)
-    assert torch.equal(outs[5], outs[4])
+        ops.set_option("gemm_kernel", 9)
+    parity.check(f"op/gemm_big_f32out/{M}x{N}x{K}", rel_l2(outs[9], want), 1e-3)
+    for kern in (4, 5):                # 9 = the default (two-slot ping-pong, round 4); 4 = four-slot ping-pong; 5 = four waves
+        assert torch.equal(outs[kern], outs[9]), kern
 
 
-@pytest.mark.parametrize("kern", [4, 5])
+@pytest.mark.parametrize("kern", [4, 5, 9])
 @pytest.mark.parametrize("res_dtype,out_f32", [("f32", True), ("bf16", False)])
 def test_gemm_big_tile_fused_epilogue(ops, ref, res_dtype, out_f32, kern, parity):
     """gelu + per-column affine + residual on the big-tile path, ragged M and N tails, in place on the residual."""
@@ -130,7 +131,7 @@ def test_gemm_big_tile_fused_epilogue(ops, ref, res_dtype, out_f32, kern, parity
                          out_f32=out_f32, out=r)
         torch.cuda.synchronize()
     finally:
-        ops.set_option("gemm_kernel", 4)
+        ops.set_option("gemm_kernel", 9)
     parity.check(f"op/gemm_big_epilogue/k{kern}/{res_dtype}", rel_l2(got.float(), want), 1e-3 if out_f32 else 4e-3)
 
 

@@ -267,7 +267,7 @@ def test_full_size_forward_matches_reference_golden(name, parity):
         b, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
         torch.cuda.synchronize()
     finally:
-        ops.set_option("gemm_kernel", 4)
+        ops.set_option("gemm_kernel", 9)
         ops.set_option("attn_var", 192)
     assert torch.isfinite(b.float()).all()
     parity.check(f"e2e/{name}/noise_pred_independent_kernels", rel_l2(b.float(), g["noise_pred"]), E2E_TOL)

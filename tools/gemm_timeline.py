@@ -67,5 +67,5 @@ for var, with_res in ((2, False), (4, False), (4, True)):
     rounds = (tiles + 255) // 256
     print(f"  kernel span {us(t_start, t_end):.1f} us for {rounds} rounds of 256 tiles = {us(t_start, t_end)/rounds:.2f} us per round; "
           f"tile starts at (us, every 256th in start order): {[round(starts[k], 1) for k in range(0, tiles, 256)]}")
-ops.set_option("gemm_kernel", 4)
+ops.set_option("gemm_kernel", 9)
 ops.set_option("gemm_var", 0)

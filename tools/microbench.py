@@ -46,7 +46,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     rb = lambda *s: torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
 
-    gvars = [tuple(int(a) for a in v.split(":")) for v in args.gemm_variants.split(",") if v] or [(4, 0)]
+    gvars = [tuple(int(a) for a in v.split(":")) for v in args.gemm_variants.split(",") if v] or [(9, 0)]
     avars = [int(v) for v in args.attn_variants.split(",") if v] or [192]
     if args.only in ("", "gemm", "gemmonly"):
       for (gk, gv) in gvars:
@@ -80,7 +80,7 @@ def main():
                 res.append(dict(kernel="vendor_blas", tag=tag, M=M, N=N, K=K, ms=ms, tflops=tf))
                 print(f"     vendor BLAS (torch.matmul) same shape          {ms:8.3f} ms  {tf:7.1f} TF/s", flush=True)
             del x, lin, out
-      ops.set_option("gemm_kernel", 4)
+      ops.set_option("gemm_kernel", 9)
       ops.set_option("gemm_var", 0)
     if args.only in ("", "fp8", "gemm"):
         print("== fp8 linear (quantise rows + 256x256x128 ping-pong GEMM on the scaled MFMA)", flush=True)
