@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--hip-graph", action="store_true",
                     help="N = 1: after the timed (eager) region, capture one whole step in a HIP graph and time the same number of "
                          "replays -- reported in a `hip_graph` block, never as `value` (SURVEY.md 8(f) item 3)")
+    ap.add_argument("--cfg-streams", action="store_true",
+                    help="N = 1: after the timed region, time the same number of steps with the two CFG forwards of a step on two HIP "
+                         "streams (sampler.denoise_step(cfg_streams=True)) -- reported in a `cfg_streams` block, never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="bound on the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true",
@@ -392,6 +395,25 @@ def main():
                             "note": "one whole denoise step (2 forwards + fw_cfg_euler_step) captured once, replayed per step; "
                                     "timestep / (cfg_scale, dsigma) / latents fed through device buffers; `value` stays the eager number"}
         del gstep
+    if args.cfg_streams and world == 1:
+        lat_s, sid = latents, step_id
+        lat_s = denoise_step(eng, sched, sid, lat_s, ins["context"], ins["context_neg"], cond, cfg_streams=True)[0]      # one untimed step
+        sid += 1
+        barrier()
+        t0 = time.time()
+        for _ in range(args.steps):
+            lat_s = denoise_step(eng, sched, sid, lat_s, ins["context"], ins["context_neg"], cond, cfg_streams=True)[0]
+            sid += 1
+        barrier()
+        dts = time.time() - t0
+        # same arithmetic per forward: the two-stream step must reproduce the one-stream step bit for bit
+        same = torch.equal(denoise_step(eng, sched, 3, ins["x"], ins["context"], ins["context_neg"], cond, cfg_streams=True)[0],
+                           denoise_step(eng, sched, 3, ins["x"], ins["context"], ins["context_neg"], cond)[0])
+        assert torch.isfinite(lat_s.float()).all()
+        out["cfg_streams"] = {"ms_per_step": 1e3 * dts / args.steps, "steps": args.steps, "one_stream_ms_per_step": 1e3 * dt / args.steps,
+                              "gain": dt / dts - 1.0, "bit_identical_to_one_stream": bool(same),
+                              "note": "the two CFG forwards of a step on two HIP streams (independent until the combine); `value` stays "
+                                      "the one-stream number"}
     if comm is not None:
         # which exchange pattern ran (the grouped q|k|v exchange falls back to one exchange per attention on a rank set where its
         # probe does not complete), what the reduced partial sums of the TP partition are rounded to, and what the bytes cost here

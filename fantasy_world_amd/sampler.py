@@ -43,15 +43,38 @@ class FlowMatchScheduler:
         return tab[step_id:step_id + 1]
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    dev = torch.device(device)
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(dev)
+    return _SIDE_STREAMS[key]
+
+
 @torch.no_grad()
 def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cfg_scale=5.0, return_prediction=False,
-                 topo=None, merge_cfg=False):
+                 topo=None, merge_cfg=False, cfg_streams=False):
     """One sampling step = 2 joint_forward calls (CFG) + combine + scheduler update (M21:289-322).
     topo (fantasy_world_amd.parallel.Topology) with two CFG groups: this rank runs only its group's forward and the two
     noise predictions are exchanged with one all-gather; the geometry prediction lives on the positive-prompt group.
-    merge_cfg (single GPU): both forwards in one pass over 2L rows (FusionEngine.joint_forward_pair; bit-identical results)."""
+    merge_cfg (single GPU): both forwards in one pass over 2L rows (FusionEngine.joint_forward_pair; bit-identical results).
+    cfg_streams (single GPU, round 4): the two forwards -- independent until the combine -- on TWO HIP streams, so the HBM-bound row
+    passes and the grid tails of one forward (7.5 % of a step's kernel time is non-MFMA work, serialised on one stream) run beside
+    the other forward's matrix kernels; same kernels, same arithmetic per forward: bit-identical results.  Needs an engine whose
+    step-invariant cache is off or already warm (its entries are produced on the stream that first asks for them)."""
     t = scheduler.timestep_on(step_id, latents.device, latents.dtype)
-    if merge_cfg and (topo is None or topo.world == 1):
+    if cfg_streams and (topo is None or topo.world == 1) and latents.is_cuda:
+        cur, side = torch.cuda.current_stream(latents.device), _side_stream(latents.device)
+        side.wait_stream(cur)                                 # inputs (latents, timestep, conditioning) were produced on `cur`
+        with torch.cuda.stream(side):
+            neg, _ = engine.joint_forward(latents, t, ctx_neg, **cond)
+        pos, pred = engine.joint_forward(latents, t, ctx_pos, return_prediction=return_prediction, **cond)
+        cur.wait_stream(side)
+        neg.record_stream(cur)                                # allocated on the side stream's pool, consumed (and freed) on `cur`
+    elif merge_cfg and (topo is None or topo.world == 1):
         pos, neg, pred = engine.joint_forward_pair(latents, t, ctx_pos, ctx_neg, return_prediction=return_prediction, **cond)
     elif topo is not None and topo.cfg_groups == 2:
         mine = ctx_pos if topo.cfg_rank == 0 else ctx_neg

@@ -247,6 +247,10 @@ SIZED_CASES = {
     # BASELINE.json configs[3] token grid (Wan2.2-Fun-A14B-Control-Camera, 81f x 720p -> latents [1,16,21,90,160], L = 75600,
     # L2 = 75705), control adapter at its real size
     "wan22_cfg4_l2_f21_90x160": (dict(num_layers=2, start_index=1), (21, 90, 160), 996.0, 512, 64, False),
+    # the reference CLI's OWN default grid (inference_wan21.py:93-128: --height 336 --width 592 --frames 81 -> latents
+    # [1,16,21,42,74]): 21 x 37 = 777 tokens per frame -- odd in both directions, L = 16317 (not a multiple of any tile size), 782
+    # VGGT tokens per frame, L2 = 16422 -- the shape a user of the unmodified script gets first (round 4)
+    "wan21_cli_l2_f21_42x74": (dict(num_layers=2, start_index=1), (21, 42, 74), 996.0, 512, 64, False),
 }
 
 

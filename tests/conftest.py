@@ -124,7 +124,7 @@ class ParityLog:
 
     def __init__(self):
         self.rows = {}
-        # Tight bounds = 1.5 x the value measured on MI355X (tools/make_parity_bounds.py from profiles/rNN/parity.json; the
+        # Tight bounds = 1.5 x (2.5 x where the checker runs on PyTorch-ROCm kernels) the value measured on MI355X (tools/make_parity_bounds.py from profiles/rNN/parity.json; the
         # kernels are deterministic, so a measured value reproduces bit for bit on any gfx950).  The bound written in the test
         # is the PHYSICAL one (what the arithmetic may cost at most); the tight one turns a silent regression inside it -- say
         # 1.2e-3 -> 3.9e-3 under a 4e-3 bound -- into a failure.  Only applied on a GPU run.
@@ -139,7 +139,7 @@ class ParityLog:
         eff = float(bound) if tight is None else min(float(bound), float(tight))
         self.rows[name] = {"measured": float(value), "bound": float(bound), "enforced": eff}
         assert value < eff, f"{name}: {value:.3e} >= {eff:.3e} (physical bound {bound:.1e}" + (
-            "" if tight is None else f", 1.5 x measured {tight:.3e}") + ")"
+            "" if tight is None else f", tight bound from measurements {tight:.3e}") + ")"
         return value
 
     def note(self, name, value):

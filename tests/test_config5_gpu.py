@@ -1,0 +1,113 @@
+"""-m gpu: BASELINE configs[4] at ITS size -- the Wan2.2 flavour on the 121-frame x 720 x 1280 grid (latents [1,16,31,90,160], L = 111 600
+DiT tokens, L2 = 111 755 VGGT tokens) -- as parity numbers instead of "ran, finite" (VERDICT r03 "J2").
+
+Checker: the REAL reference (oracle/_ref bundle) -- a 2-block Wan2.2 FantasyWorldFusionModel (1 preconditioning block + 1 IRG block:
+every kind of block the 40-block model has; depth is pinned separately, tests/test_full_depth_gpu.py) -- on PyTorch-ROCm in fp32, which
+reproduces its own CPU golden to 1.3e-6 on this box (`ref_on_gpu/wan22/reference_rocm_fp32_vs_golden`).  Three comparisons:
+  * bf16 engine against the fp32 reference (the same plateau as at every other size is the expectation);
+  * fp8-linear engine (`precision="fp8"`) against the reference with the SAME linears computed by the reference's fp8 linear: the modules
+    `enable_vram_management(module_map={nn.Linear: AutoWrappedLinear}, computation_dtype=float8_e4m3fn)` would swap
+    (diffsynth_wan22/vram_management/layers.py:113-166) are swapped here for a module whose forward is `AutoWrappedLinear.fp8_linear`
+    written by its definition (oracle/fw_oracle.py:fp8_linear -- bit-identical to the real torch._scaled_mm call,
+    tests/test_reference_on_gpu.py::test_fp8_linear_against_the_real_scaled_mm; the real call refuses fp32 activations);
+  * fp8 attention (`fp8_attention=True`) has no reference semantics (the reference defines fp8 for linears only): its distance from the
+    fp8-linear checker is RECORDED, under the same physical bound as at config-1 size.
+"""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import ref_locate
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_locate.available(), reason="reference not mounted / staged")]
+
+DEV = "cuda:0"
+FP8_SITES = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v", "cross_attn.o",
+             "ffn.0", "ffn.2")
+
+
+class _Fp8LinearByDefinition(torch.nn.Module):
+    """Stand-in for AutoWrappedLinear(computation_dtype=float8_e4m3fn) around one nn.Linear of the reference."""
+
+    def __init__(self, lin):
+        super().__init__()
+        self.weight, self.bias = lin.weight, lin.bias
+
+    def forward(self, x, *a, **k):
+        from oracle import fw_oracle
+        return fw_oracle.fp8_linear(x, self.weight, self.bias)
+
+
+def _swap_fp8(model, cfg):
+    blocks = [model.pipe.dit.blocks[b] for b in range(cfg.start_index)] + [ib.x_dit for ib in model.IRGBlock]
+    n = 0
+    for blk in blocks:
+        for site in FP8_SITES:
+            owner_name, leaf = site.split(".")
+            owner = getattr(blk, owner_name)
+            lin = owner[int(leaf)] if leaf.isdigit() else getattr(owner, leaf)
+            assert isinstance(lin, torch.nn.Linear), (site, type(lin))
+            if leaf.isdigit():
+                owner[int(leaf)] = _Fp8LinearByDefinition(lin)
+            else:
+                setattr(owner, leaf, _Fp8LinearByDefinition(lin))
+            n += 1
+    return n
+
+
+def test_config5_grid_against_the_reference(parity):
+    from fantasy_world_amd import config as fwc, synth, install, uninstall
+    from fantasy_world_amd.hip_ops import HipOps
+    from oracle import ref_harness
+    cfg = fwc.plumbing22(num_layers=2, start_index=1)
+    weights = synth.LazyWeights(synth.weight_spec(cfg), device=DEV)
+    model = ref_harness.build_reference_wan22(cfg, weights=weights, heads_cfg=fwc.HeadsConfig.e2e_small())
+    model.to(device=DEV, dtype=torch.float32)
+    model.pipe.device, model.pipe.torch_dtype, model.device = DEV, torch.float32, DEV
+    f, h2, w2 = 31, 90, 160
+    ins = synth.make_inputs(cfg, f, h2, w2, seed=21, device=DEV, dtype=torch.float32)
+    L = f * (h2 // 2) * (w2 // 2)
+    assert L == 111600
+    kw = dict(timestep=ins["timestep"], context=ins["context"], y=ins["y"], use_gradient_checkpointing=False, camera_token=None,
+              control_camera_latents_input=ins["control_camera_latents_input"], uncond=False, return_prediction=False)
+    ops = HipOps(DEV)
+    with torch.no_grad():
+        want32, _ = model.joint_forward(ins["x"], **kw)                        # the reference, fp32, PyTorch-ROCm
+    torch.cuda.synchronize()
+
+    got = {}
+    for tag, opts in (("bf16", {}), ("fp8_linears", dict(precision="fp8"))):
+        eng = install(model, ops=ops, merge_cfg=False, **opts)
+        got[tag], _ = model.joint_forward(ins["x"], **kw)
+        torch.cuda.synchronize()
+        uninstall(model)
+        del eng
+    # fp8 attention is an engine option the install() boundary does not expose (parity unpinned): built directly
+    from fantasy_world_amd.engine import FusionEngine
+    params = dict(model.named_parameters())
+    eng = FusionEngine(cfg, params.__getitem__, ops, precision="fp8", fp8_attention=True)
+    ekw = {k: v for k, v in kw.items() if k not in ("timestep", "context", "use_gradient_checkpointing")}
+    got["fp8_all"], _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **ekw)
+    torch.cuda.synchronize()
+    del eng, params
+    torch.cuda.empty_cache()
+
+    assert _swap_fp8(model, cfg) == 2 * len(FP8_SITES)
+    with torch.no_grad():
+        want8, _ = model.joint_forward(ins["x"], **kw)                         # the reference with the fp8 linear in those modules
+    torch.cuda.synchronize()
+
+    tagp = "config5/wan22_l2_f31_90x160"
+    e = {"bf16_vs_ref_fp32": rel_l2(got["bf16"], want32), "fp8_linears_vs_ref_fp8": rel_l2(got["fp8_linears"], want8),
+         "fp8_linears_vs_ref_fp32": rel_l2(got["fp8_linears"], want32), "ref_fp8_vs_ref_fp32": rel_l2(want8, want32),
+         "fp8_attention_vs_ref_fp8": rel_l2(got["fp8_all"], want8)}
+    print(tagp, {k: f"{v:.2e}" for k, v in e.items()})
+    assert all(torch.isfinite(t.float()).all() for t in got.values())
+    parity.check(f"{tagp}/bf16_engine_vs_reference_fp32", e["bf16_vs_ref_fp32"], 8e-3)
+    parity.check(f"{tagp}/fp8_linear_engine_vs_reference_with_fp8_linears", e["fp8_linears_vs_ref_fp8"], 2e-2)
+    parity.note(f"{tagp}/reference_with_fp8_linears_vs_reference_fp32", e["ref_fp8_vs_ref_fp32"])
+    parity.check(f"{tagp}/fp8_linear_engine_vs_reference_fp32", e["fp8_linears_vs_ref_fp32"], 1e-1)
+    # parity UNPINNED by construction: recorded, bounded physically only
+    parity.check(f"{tagp}/fp8_attention_engine_vs_reference_with_fp8_linears__unpinned", e["fp8_attention_vs_ref_fp8"], 1e-1)

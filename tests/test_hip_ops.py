@@ -157,15 +157,21 @@ def test_gemm_rows_do_not_depend_on_their_tile(ops, N, K, act):
         assert torch.equal(both[i * M:(i + 1) * M], alone), f"sample {i}"
 
 
+# DiT token counts of BASELINE configs 2 / 4 / 5 (81f x 480 x 832; 81f x 720 x 1280; 121f x 720 x 1280) and of config 5's merged CFG pass
+# (both samples stacked along the rows: 2 x 111 600; M x N passes 2^31 elements there)
+FULL_M = [pytest.param(32760, id="cfg2_L32760"), pytest.param(75600, id="cfg4_L75600"), pytest.param(111600, id="cfg5_L111600"),
+          pytest.param(223200, id="cfg5_merged_2x111600")]
+
+
+@pytest.mark.parametrize("M", FULL_M)
 @pytest.mark.parametrize("N,K,tag", [(15360, 5120, "qkv"), (13824, 5120, "ffn0"), (5120, 13824, "ffn2")])
-def test_gemm_full_size_properties(ops, N, K, tag, parity):
-    """BASELINE config-2 shapes (M = L = 32760 rows; every tile, every k-slab of the kernel the forward runs), two size-independent
+def test_gemm_full_size_properties(ops, M, N, K, tag, parity):
+    """BASELINE config-2 / 4 / 5 shapes (M = L rows; every tile, every k-slab of the kernel the forward runs), two size-independent
     properties instead of a CPU reference:
       * selection, BIT-EXACT: with one-hot rows (row m has a single 1.0 at column j(m)) the GEMM returns W[:, j(m)] + bias -- every
         product is exact and every other term is 0, so fp32 out equals the gathered weights bit for bit and bf16 out their rounding;
         a wrong row / column / k-slab address anywhere in the grid shows;
       * a checksum of checksums on random data: sum_mn out[m, n] = sum_k (sum_m x[m, k]) (sum_n W[n, k]) + M sum_n b[n], in fp64."""
-    M = 32760
     g = torch.Generator(device="cuda").manual_seed(5)
     w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(N, device="cuda", generator=g) * 0.1
@@ -184,7 +190,9 @@ def test_gemm_full_size_properties(ops, N, K, tag, parity):
     total = out.double().sum().item()
     expect = (x.double().sum(0) * w.double().sum(0)).sum().item() + M * b.double().sum().item()
     scale = out.double().abs().sum().item()
-    parity.check(f"op/gemm_full_size_checksum/{tag}", abs(total - expect) / scale, 1e-6)
+    parity.check(f"op/gemm_full_size_checksum/{tag}" + ("" if M == 32760 else f"/M{M}"), abs(total - expect) / scale, 1e-6)
+    del out, x
+    torch.cuda.empty_cache()
 
 
 def test_empty_inputs(ops):
@@ -359,27 +367,31 @@ def test_attention_all_scores_far_below_zero(attn_variant, ops, ref, parity, req
     parity.check(f"op/{request.node.name}/0", rel_l2(got.float(), want), 4e-3)
 
 
-def test_attention_full_length_properties(attn_variant, ops, parity, request):
-    """BASELINE config-2 size (L = 32760, hd 128): rows of softmax sum to 1 => V = const gives O = const, and
-    sampled query rows match an fp32 evaluation of the same rows."""
-    heads, hd, L = 2, 128, 32760
+@pytest.mark.parametrize("L,batch", [pytest.param(32760, 1, id="cfg2_L32760"), pytest.param(75600, 1, id="cfg4_L75600"),
+                                     pytest.param(111600, 1, id="cfg5_L111600"), pytest.param(111600, 2, id="cfg5_merged_batch2")])
+def test_attention_full_length_properties(attn_variant, ops, parity, request, L, batch):
+    """BASELINE config-2 / 4 / 5 sizes (L = 32760 / 75600 / 111600 keys, hd 128; batch 2 = the merged CFG pass): rows of softmax sum
+    to 1 => V = const gives O = const, and sampled query rows match an fp32 evaluation of the same rows."""
+    heads, hd = 2, 128
     g = torch.Generator(device="cuda").manual_seed(0)
-    q = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
-    k = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
-    v = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    q = torch.randn(batch * L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    k = torch.randn(batch * L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    v = torch.randn(batch * L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     pre = attn_variant >= 64
     qs = (q.float() * ops.q_scale(hd)).to(torch.bfloat16) if pre else q
     sc = 0.6931471805599453 if pre else 1.0 / math.sqrt(hd)
     ones = torch.full_like(v, 0.5)
-    o1 = ops.attention(qs, k, ones, heads, hd, q_prescaled=pre)
+    o1 = ops.attention(qs, k, ones, heads, hd, batch=batch, q_prescaled=pre)
     assert (o1.float() - 0.5).abs().max().item() < 4e-3
-    o = ops.attention(qs, k, v, heads, hd, q_prescaled=pre)
-    rows = torch.tensor([0, 1, 255, 256, 9999, 16383, 32503, 32759], device="cuda")
-    for h in range(heads):
-        sl = slice(h * hd, (h + 1) * hd)
-        s = (qs[rows][:, sl].float() @ k[:, sl].float().t()) * sc
-        want = torch.softmax(s, dim=-1) @ v[:, sl].float()
-        parity.check(f"op/{request.node.name}/0", rel_l2(o[rows][:, sl].float(), want), 6e-3)
+    o = ops.attention(qs, k, v, heads, hd, batch=batch, q_prescaled=pre)
+    rows = torch.tensor([0, 1, 255, 256, 9999, 16383, 32503, 32759, L - 257, L - 1], device="cuda")
+    for b in range(batch):                                  # a sample only attends to its own keys
+        kb, vb = k[b * L:(b + 1) * L], v[b * L:(b + 1) * L]
+        for h in range(heads):
+            sl = slice(h * hd, (h + 1) * hd)
+            s = (qs[b * L + rows][:, sl].float() @ kb[:, sl].float().t()) * sc
+            want = torch.softmax(s, dim=-1) @ vb[:, sl].float()
+            parity.check(f"op/{request.node.name}/0", rel_l2(o[b * L + rows][:, sl].float(), want), 6e-3)
 
 
 def test_attention_rejects_bad_head_dim(attn_variant, ops):
@@ -481,21 +493,25 @@ def test_qk_prep_ln_head_rope2d(ops, ref, parity, request):
     parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
 
 
-def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity):
-    """BASELINE config-2 sizes for the row-wise passes around the GEMMs (every row is independent, so a sample of rows pins the
-    launch at full size against the CPU oracle ops): the modulated LayerNorm of the fp32 DiT stream [32760, 5120], the affine +
-    modulated LayerNorm of the VGGT stream [32865, 1024], the DiT q/k pass (RMSNorm over 5120 + interleaved 3-D RoPE + q scale) on
-    [32760, 5120] and the VGGT q/k pass (per-head LayerNorm + 2-D RoPE) on two whole frames of [32865, 1024]."""
+@pytest.mark.parametrize("F,h,w", [pytest.param(21, 30, 52, id="cfg2_81f_480x832"), pytest.param(21, 45, 80, id="cfg4_81f_720x1280"),
+                                   pytest.param(31, 45, 80, id="cfg5_121f_720x1280")])
+def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity, F, h, w):
+    """BASELINE config-2 / 4 / 5 sizes for the row-wise passes around the GEMMs (every row is independent, so a sample of rows pins the
+    launch at full size against the CPU oracle ops): the modulated LayerNorm of the fp32 DiT stream [L, 5120], the affine +
+    modulated LayerNorm of the VGGT stream [L2, 1024], the DiT q/k pass (RMSNorm over 5120 + interleaved 3-D RoPE + q scale) on
+    [L, 5120] and the VGGT q/k pass (per-head LayerNorm + 2-D RoPE) on two whole frames of [L2, 1024]."""
     from fantasy_world_amd import rope
     g = torch.Generator(device="cuda").manual_seed(71)
-    L, L2, P = 32760, 32865, 1565
-    rows = torch.tensor([0, 1, 63, 64, 255, 256, 4095, 4096, 8191, 16384, 20000, 32503, 32758, 32759])
+    P = 5 + h * w
+    L, L2 = F * h * w, F * P
+    tag = "" if (F, h, w) == (21, 30, 52) else f"/L{L}"
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, 4095, 4096, 8191, 16384, 20000, 32503, L - 2, L - 1])
     # LayerNorm, DiT stream
     x = torch.randn(L, 5120, device="cuda", generator=g) * 2 + 0.3
     sc, sh = rnd(5120, seed=72, scale=0.3), rnd(5120, seed=73, scale=0.3)
     got = ops.layernorm(x, scale=sc.cuda(), shift=sh.cuda(), eps=1e-6)
     want = ref.layernorm(x[rows.cuda()].cpu(), scale=sc, shift=sh, eps=1e-6)
-    parity.check("op/full_size_rows/layernorm_mod_5120", rel_l2(got[rows.cuda()].float(), want), 4e-3)
+    parity.check("op/full_size_rows/layernorm_mod_5120" + tag, rel_l2(got[rows.cuda()].float(), want), 4e-3)
     # a constant row has zero variance: the output is the shift, exactly (values with exact fp32 sums)
     x[rows.cuda()] = 0.5
     got = ops.layernorm(x, scale=sc.cuda(), shift=sh.cuda(), eps=1e-6)
@@ -505,31 +521,31 @@ def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity):
     t = torch.randn(L2, 1024, device="cuda", generator=g)
     w, b = 1 + rnd(1024, seed=74, scale=0.1), rnd(1024, seed=75, scale=0.1)
     sc, sh = rnd(1024, seed=76, scale=0.3), rnd(1024, seed=77, scale=0.3)
-    rows2 = torch.cat([rows, torch.tensor([32760, 32864])])
+    rows2 = torch.cat([rows, torch.tensor([L2 - 105, L2 - 1])])
     got = ops.layernorm(t, w.cuda(), b.cuda(), sc.cuda(), sh.cuda(), 1e-5)
     want = ref.layernorm(t[rows2.cuda()].cpu(), w, b, sc, sh, 1e-5)
-    parity.check("op/full_size_rows/layernorm_affine_mod_1024", rel_l2(got[rows2.cuda()].float(), want), 4e-3)
+    parity.check("op/full_size_rows/layernorm_affine_mod_1024" + tag, rel_l2(got[rows2.cuda()].float(), want), 4e-3)
     del t, got
     # DiT q pass: 40 heads x 128, full-width RMSNorm, 3-D RoPE, q pre-scale
     heads, hd = 40, 128
-    tab = rope.rope3d_table(hd, 21, 30, 52)
+    tab = rope.rope3d_table(hd, F, h, w)
     q = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     nw = 1 + rnd(heads * hd, seed=78, scale=0.1)
     qr = q[rows.cuda()].float().cpu()
     ref.qk_prep(qr, heads, hd, "rms_full", nw, None, 1e-6, "interleaved", tab[rows], out_scale=ops.q_scale(hd))
     ops.qk_prep(q, heads, hd, "rms_full", nw.cuda(), None, 1e-6, "interleaved", tab.cuda(), out_scale=ops.q_scale(hd))
-    parity.check("op/full_size_rows/qk_prep_rms_rope3d", rel_l2(q[rows.cuda()].float(), qr), 4e-3)
+    parity.check("op/full_size_rows/qk_prep_rms_rope3d" + tag, rel_l2(q[rows.cuda()].float(), qr), 4e-3)
     del q
-    # VGGT k pass: 16 heads x 64, per-head LayerNorm, 2-D RoPE with table row = row % P: frames 0 and 20 whole
+    # VGGT k pass: 16 heads x 64, per-head LayerNorm, 2-D RoPE with table row = row % P: the first and the last frame whole
     heads, hd = 16, 64
-    tab2 = rope.rope2d_table(hd, 30, 52, 5)
+    tab2 = rope.rope2d_table(hd, h, w, 5)
     k = torch.randn(L2, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     nw, nb = 1 + rnd(hd, seed=79, scale=0.1), rnd(hd, seed=80, scale=0.1)
-    fr = torch.cat([torch.arange(0, P), torch.arange(20 * P, 21 * P)])
+    fr = torch.cat([torch.arange(0, P), torch.arange((F - 1) * P, F * P)])
     kr = k[fr.cuda()].float().cpu()
     ref.qk_prep(kr, heads, hd, "ln_head", nw, nb, 1e-5, "half2d", tab2)
     ops.qk_prep(k, heads, hd, "ln_head", nw.cuda(), nb.cuda(), 1e-5, "half2d", tab2.cuda())
-    parity.check("op/full_size_rows/qk_prep_ln_head_rope2d", rel_l2(k[fr.cuda()].float(), kr), 4e-3)
+    parity.check("op/full_size_rows/qk_prep_ln_head_rope2d" + tag, rel_l2(k[fr.cuda()].float(), kr), 4e-3)
 
 
 def test_qk_prep_rope_only_hd96_with_identity_rows(ops, ref, parity, request):

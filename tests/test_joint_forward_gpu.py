@@ -222,7 +222,7 @@ def test_hip_matches_cpu_oracle_on_negative_prompt_and_uncond(case_l2):
         del eng
 
 
-FULL_SIZE_GOLDENS = ["wan21_cfg2_l2_f21_60x104", "wan22_cfg4_l2_f21_90x160"]
+FULL_SIZE_GOLDENS = ["wan21_cfg2_l2_f21_60x104", "wan22_cfg4_l2_f21_90x160", "wan21_cli_l2_f21_42x74"]
 
 
 @pytest.mark.parametrize("name", FULL_SIZE_GOLDENS)

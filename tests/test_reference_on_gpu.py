@@ -39,10 +39,13 @@ def _cast(kw, dtype):
     return {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kw.items()}
 
 
-def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
+@pytest.mark.parametrize("steps", [3, 5])
+def test_reference_generate_video_runs_on_hip_path(case_pred, parity, steps):
     """The reference's own sampling loop (scheduler, CFG combine, `latents.to('cuda')`, return_prediction on the last step)
-    around the rebound joint_forward + get_pose_fea, 3 steps, against the reference itself on PyTorch-ROCm fp32; the reference's
-    bf16-autocast configuration (what inference_wan21.py runs) is measured beside it as the yardstick."""
+    around the rebound joint_forward + get_pose_fea, against the reference itself on PyTorch-ROCm fp32; the reference's
+    bf16-autocast configuration (what inference_wan21.py runs) is measured beside it as the yardstick.  3 steps: learn the CFG pair,
+    one merged pass, the last step with the prediction; 5 steps: CfgPairing's STEADY state (steps 2-4 all merged passes answered from
+    the stash) is on the path before the last step."""
     from oracle import ref_harness
     from fantasy_world_amd import install, uninstall, synth
     from fantasy_world_amd.hip_ops import HipOps
@@ -51,14 +54,19 @@ def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
     W.update(synth.make_pose_encoder_weights())
     model = _to_dev(ref_harness.build_reference_wan21(c.cfg, weights=W, heads_cfg=c.hc), torch.float32)
     assert not model._fw_unused
-    kw = _gen_kwargs(c, steps=3)            # step 1 learns the CFG pair, step 2 runs the merged pass, step 3 (last) returns the prediction
+    kw = _gen_kwargs(c, steps=steps)        # step 1 learns the CFG pair, steps 2.. run the merged pass, the last step returns the prediction
+    sfx = "" if steps == 3 else f"/{steps}_steps"
     want, wpred = model.generate_video(**kw)                               # the reference, fp32, PyTorch-ROCm kernels
     torch.cuda.synchronize()
 
     eng = install(model, ops=HipOps(DEV))
+    passes = []
+    orig = eng._forward
+    eng._forward = lambda x, t, contexts, *a, **k: (passes.append(len(contexts)), orig(x, t, contexts, *a, **k))[1]
     got, pred = model.generate_video(**kw)                                 # the SAME call on the HIP path
     torch.cuda.synchronize()
     uninstall(model)
+    assert passes == [1, 1] + [2] * (steps - 1), passes                    # two plain forwards, then ONE merged pass per step
     assert got.shape == want.shape and got.dtype == want.dtype and eng.heads_cfg is not None
     e_lat = rel_l2(got, want)
 
@@ -74,7 +82,7 @@ def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
     uninstall(model)
     assert got16.dtype == ref16.dtype == torch.bfloat16
     e_ref16_vs_fp32, e_16 = rel_l2(ref16.float(), want), rel_l2(got16.float(), ref16.float())
-    parity.note("ref_on_gpu/generate_video/latents_reference_bf16_config_vs_reference_fp32", e_ref16_vs_fp32)
+    parity.note("ref_on_gpu/generate_video/latents_reference_bf16_config_vs_reference_fp32" + sfx, e_ref16_vs_fp32)
     print(f"latents: HIP vs reference, fp32 I/O {e_lat:.2e}; HIP vs reference, both in the bf16 inference configuration {e_16:.2e}; "
           f"reference bf16 configuration vs reference fp32 {e_ref16_vs_fp32:.2e}")
     # Two sampling steps: the CFG combine neg + 5 (pos - neg) multiplies a forward's relative error by ~sqrt(5^2 + 4^2) = 6.4 and the
@@ -82,13 +90,13 @@ def test_reference_generate_video_runs_on_hip_path(case_pred, parity):
     # against the reference in fp32; the bf16 inference configuration against the reference in ITS bf16 configuration (which
     # rounds the timestep to bf16, model_wan21.py:292-293: 833.3 -> 832, worth 1e-1 on the latents against the fp32 run -- a
     # property of the reference, reproduced, not an error of either side).
-    parity.check("ref_on_gpu/generate_video/latents_hip_vs_ref_fp32", e_lat, 4e-2)
-    parity.check("ref_on_gpu/generate_video/latents_hip_vs_ref_both_bf16_config", e_16, 4e-2)
+    parity.check("ref_on_gpu/generate_video/latents_hip_vs_ref_fp32" + sfx, e_lat, 4e-2)
+    parity.check("ref_on_gpu/generate_video/latents_hip_vs_ref_both_bf16_config" + sfx, e_16, 4e-2)
     # the prediction of the reference on a GPU is computed under ITS bf16 autocast (vggt.py:136): both sides carry bf16 noise, on
     # top of the latents' divergence above
     for k in PRED_KEYS:
         assert pred[k].shape == wpred[k].shape
-        parity.check(f"ref_on_gpu/generate_video/{k}", rel_l2(pred[k].float(), wpred[k].float()), 6e-2)
+        parity.check(f"ref_on_gpu/generate_video/{k}" + sfx, rel_l2(pred[k].float(), wpred[k].float()), 6e-2)
 
 
 def test_install_blocks_under_reference_joint_forward_on_hip(case_depth, parity):
