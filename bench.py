@@ -108,6 +108,17 @@ def forward_flops(cfg, L, L2, S, P, Lc, Li):
     return 2.0 * macs
 
 
+def attention_cap(hd):
+    """What bounds an attention launch of head size hd on this SIMD (docs/kernels.md, "attention: the cap"): per 64-key tile of 32 query
+    rows a wave spends 8 hd cycles in MFMAs and ~533 cycles in the softmax's VALU work (32 v_exp_f32 + 32 adds + 16 packs), and the two
+    do NOT overlap between the two waves of a SIMD -- the sum fits the measured per-tile times of hd 128 / 96 / 64 to 1 %
+    (profiles/r03/microbench_attention_variants.txt).  The matrix-pipe fraction is therefore capped at hd / (hd + 66.6) of the peak at
+    the clock the chip sustains (~1.9-2.0 of 2.4 GHz on random data), whatever the schedule."""
+    cap = hd / (hd + 66.6)
+    return {"mfma_frac_at_sustained_clock": round(cap, 3), "frac_of_2p5_pf_at_1p95_ghz": round(cap * 1.95 / 2.4, 3),
+            "model": "8*hd MFMA cycles + 533 VALU cycles per 64-key tile and wave, not overlapping"}
+
+
 def dry_run(args):
     """No GPU: rendezvous (gloo), CFG groups, every collective of the sequence shard on small CPU tensors, barrier +
     max-over-ranks timing, the JSON line.  Proves the launcher and the topology code; measures nothing."""
@@ -323,6 +334,8 @@ def main():
         kernels[name] = {"avg_launch_ms": ms, "launches_timed": n,
                          "tflops": None if fl is None else fl / (ms * 1e-3) / 1e12,
                          "frac_of_bf16_peak": None if fl is None else fl / (ms * 1e-3) / MFMA_BF16_PEAK}
+        if name.startswith("attn_hd") and fl is not None:
+            kernels[name]["roofline_cap"] = attention_cap(int(name[7:].split("_")[0]))
     # HBM-side traffic of the dominant kernel: measured with rocprofv3 PMC counters in separate passes (FETCH_SIZE, WRITE_SIZE)
     # as MI355X_MICROARCH.md prescribes, recorded under profiles/ with provenance; bench.py only reports the stored measurement
     # (a PMC pass cannot run inside the timed process).  Valid for the headline launch shape only.
@@ -330,7 +343,7 @@ def main():
     headline = (not wan22 and args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
                 and args.precision == "bf16")
     if headline and sp == 1:
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                     traffic = nb * float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])    # merged CFG: batch 2 per launch
@@ -367,7 +380,8 @@ def main():
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
                      "flops_per_launch": attn_flops, "traffic": traffic,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*/pmc_traffic.json)",
-                     "algorithmic_bytes_per_launch": nb * 4.0 * L * cfg.dim * 2 / sp / n_groups},
+                     "algorithmic_bytes_per_launch": nb * 4.0 * L * cfg.dim * 2 / sp / n_groups,
+                     "roofline_cap": attention_cap(cfg.head_dim)},
         "kernels": kernels,
     }
     if args.precision == "fp8":

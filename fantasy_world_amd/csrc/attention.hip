@@ -693,7 +693,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     // Round 3: the tile loop unrolled by the ring depth, so the ring slot of every K / Vt fragment read is a compile-time constant
     // and folds into the ds_read's immediate offset.  With run-time slots the loop spent 27 of its 108 VALU instructions per 64-key
     // tile (hd 128) on LDS addresses (16 v_add_u32, 9 v_or_b32, 2 v_lshl_add) -- and VALU cycles ADD to the matrix cycles on this
-    // SIMD.
+    // SIMD (docs/kernels.md, "attention: the cap").
     constexpr bool UNR = (VAR & 64) != 0;
     constexpr int NS = (VAR & 2) ? 2 : 1;     // 32-row sub-blocks per wave: 2 = one wave per SIMD owning 64 query rows
     constexpr int NW = 8 / NS;                // waves per work-group (256 query rows either way)

@@ -1,7 +1,7 @@
 // bf16 MFMA GEMM with fused epilogue for gfx950:  C = epi(A[M,K] * W[N,K]^T)
 //
 // Three kernels (round 1 carried six; the superseded generations -- first 2-stage staggered kernel, 5-deep half-slab ring,
-// compiler-ordered four-wave kernel, first ping-pong kernel -- were removed in round 2, their numbers are in DESIGN.md section 4):
+// compiler-ordered four-wave kernel, first ping-pong kernel -- were removed in round 2, their numbers are in docs/history/DESIGN_r03.md section 4):
 //   gemm_bf16_pp2_kernel   256x256x64, 8 waves in two groups running LOAD || MFMA ping-pong: every big token-major GEMM (default)
 //   gemm_bf16_w4b_kernel   256x256x64, 4 waves with 128x128 wave tiles, hand-ordered single instruction stream: the INDEPENDENT
 //                          implementation the full-size agreement tests compare the default path with (FW_GEMM_KERNEL=5)
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4b_kernel(GemmArgs p) {
     // (1 KiB at 64 B/clk) and BLOCKS the issuing wave until it is accepted: four waves issuing their pieces together serialise
     // behind each other (~60 cycles each, matrix pipe idle -- measured: +1000 cycles per slab, exactly 64 pieces x 16 cycles).  So
     // the pieces are spread over three k-steps (one per 3 MFMAs) and the waves take DIFFERENT MFMA slots (slot = 3 i + wave % 3)
-    // -- which, measured, changes nothing either way (1100 TF/s spread or bunched): the cost follows the BYTES, see DESIGN.md.
+    // -- which, measured, changes nothing either way (1100 TF/s spread or bunched): the cost follows the BYTES, see docs/kernels.md.
     const int dslot = wave % 3;
     auto kstep = [&](auto cur_tag, auto read_tag, auto dma_tag, int rst, int rks, int dst, int dk) {
         constexpr int CUR = decltype(cur_tag)::value;

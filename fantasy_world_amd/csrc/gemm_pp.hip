@@ -56,6 +56,8 @@ __device__ unsigned long long g_pp_ts[2 * 4 * 8];      // TIMING build: [group][
 // Measured and NOT kept (profiles/r04/gemm_ab_call5_early_barrier_is_slower.txt): executing the barrier that ends a burst 4 / 8 / 12 MFMAs
 // before the burst's end, so that the other group starts while this one's last MFMAs drain (the phase timeline shows 120-180 cycles per
 // hand-over): -10 % in all three forms (1247-1252 against 1387 TF/s) -- two waves of a SIMD issuing MFMAs at once is worse than the gap.
+// (Also measured and not kept: the accumulators pinned in the accumulation half of the register file through asm MFMAs with "+a"
+//  operands -- bit-identical, -0.7 %, profiles/r04/gemm_ab_call10_agpr_accumulators_no_gain.txt.)
 template <int TS>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp4_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[P4_LDS];

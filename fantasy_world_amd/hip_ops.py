@@ -98,7 +98,7 @@ def load_library(path: str = LIB_PATH):
         fn.argtypes = args
     lib.fw_attention_workspace_bytes.restype = i64
     lib.fw_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    if lib.fw_abi_version() != 10:
+    if lib.fw_abi_version() != 11:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
     _lib = lib
     return lib

@@ -20,7 +20,7 @@ Two levels, chosen from what the path offers and what the xGMI mesh (7 point-to-
        any head count that does not divide: all-gather of the rotated rows (q|v1: 151 MB, k|v2: 151 MB per IRG block).
    Head/FFN-column tensor parallelism (the NVSwitch habit) would instead all-reduce the full [L,5120] activation three times
    per DiT block (1.76 GB received per GPU per block, partial sums rounded to bf16, cross-GPU statistics for the full-width
-   q/k RMSNorm) -- see DESIGN.md section 6 for the byte table.
+   q/k RMSNorm) -- see docs/multi_gpu.md for the byte table.
 
 Layout: DiT tokens are split into contiguous row ranges (L = 32760 = 4 * 8190), VGGT tokens by whole frames (frame attention
 is per frame; 21 frames over 4 ranks = 6,5,5,5).

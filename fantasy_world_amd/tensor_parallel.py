@@ -3,7 +3,7 @@
     FW_PARALLEL=tp python bench.py --gpus 8          # 2 CFG groups x TP 4   (parallel.make_topology(mode="tp"))
     FW_PARALLEL=sp python bench.py --gpus 8          # 2 CFG groups x 4-way sequence shard with head all-to-all (the default)
 
-Both partitions run the same kernels on the same model; which one wins on the xGMI mesh is a measurement (DESIGN.md section 6
+Both partitions run the same kernels on the same model; which one wins on the xGMI mesh is a measurement (docs/multi_gpu.md
 gives the byte table that made the sequence shard the default; `bench.py`'s `comm` block reports the bytes and the exposed
 time of either).  This module is the TP side:
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 10
+#define FW_ABI_VERSION 11
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */

@@ -90,7 +90,7 @@ def sdpa(q, k, v, num_heads):
 # enable_vram_management(dit, module_map={nn.Linear: AutoWrappedLinear}, computation_dtype=float8_e4m3fn) would make them
 # (diffsynth_wan21/vram_management/layers.py:145-166; diffsynth_wan22/vram_management/layers.py:113-151).  Set through
 # joint_forward(fp8_linears=True); the camera-adapter processor's small linears keep full precision (the engine's choice, stated in
-# DESIGN.md -- the reference defines no fp8 run of the fusion model at all).
+# docs/parity.md -- the reference defines no fp8 run of the fusion model at all).
 _FP8 = {"on": False}
 _FP8_SITES = (".self_attn.q", ".self_attn.k", ".self_attn.v", ".self_attn.o", ".cross_attn.q", ".cross_attn.k", ".cross_attn.v",
               ".cross_attn.o", ".cross_attn.k_img", ".cross_attn.v_img", ".ffn.0", ".ffn.2")

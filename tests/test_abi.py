@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(hip_ops.SYMBOLS) == declared, (sorted(hip_ops.SYMBOLS), declared)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.fw_abi_version() == 10
+    assert lib.fw_abi_version() == 11
 
 
 def test_no_cpu_fallback():

@@ -493,18 +493,18 @@ def test_qk_prep_ln_head_rope2d(ops, ref, parity, request):
     parity.check(f"op/{request.node.name}/0", rel_l2(xg.float(), xr), 4e-3)
 
 
-@pytest.mark.parametrize("F,h,w", [pytest.param(21, 30, 52, id="cfg2_81f_480x832"), pytest.param(21, 45, 80, id="cfg4_81f_720x1280"),
-                                   pytest.param(31, 45, 80, id="cfg5_121f_720x1280")])
-def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity, F, h, w):
+@pytest.mark.parametrize("F,gh,gw", [pytest.param(21, 30, 52, id="cfg2_81f_480x832"), pytest.param(21, 45, 80, id="cfg4_81f_720x1280"),
+                                     pytest.param(31, 45, 80, id="cfg5_121f_720x1280")])
+def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity, F, gh, gw):
     """BASELINE config-2 / 4 / 5 sizes for the row-wise passes around the GEMMs (every row is independent, so a sample of rows pins the
     launch at full size against the CPU oracle ops): the modulated LayerNorm of the fp32 DiT stream [L, 5120], the affine +
     modulated LayerNorm of the VGGT stream [L2, 1024], the DiT q/k pass (RMSNorm over 5120 + interleaved 3-D RoPE + q scale) on
     [L, 5120] and the VGGT q/k pass (per-head LayerNorm + 2-D RoPE) on two whole frames of [L2, 1024]."""
     from fantasy_world_amd import rope
     g = torch.Generator(device="cuda").manual_seed(71)
-    P = 5 + h * w
-    L, L2 = F * h * w, F * P
-    tag = "" if (F, h, w) == (21, 30, 52) else f"/L{L}"
+    P = 5 + gh * gw
+    L, L2 = F * gh * gw, F * P
+    tag = "" if (F, gh, gw) == (21, 30, 52) else f"/L{L}"
     rows = torch.tensor([0, 1, 63, 64, 255, 256, 4095, 4096, 8191, 16384, 20000, 32503, L - 2, L - 1])
     # LayerNorm, DiT stream
     x = torch.randn(L, 5120, device="cuda", generator=g) * 2 + 0.3
@@ -528,7 +528,7 @@ def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity, F, h, w):
     del t, got
     # DiT q pass: 40 heads x 128, full-width RMSNorm, 3-D RoPE, q pre-scale
     heads, hd = 40, 128
-    tab = rope.rope3d_table(hd, F, h, w)
+    tab = rope.rope3d_table(hd, F, gh, gw)
     q = torch.randn(L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     nw = 1 + rnd(heads * hd, seed=78, scale=0.1)
     qr = q[rows.cuda()].float().cpu()
@@ -538,7 +538,7 @@ def test_row_passes_at_full_size_on_sampled_rows(ops, ref, parity, F, h, w):
     del q
     # VGGT k pass: 16 heads x 64, per-head LayerNorm, 2-D RoPE with table row = row % P: the first and the last frame whole
     heads, hd = 16, 64
-    tab2 = rope.rope2d_table(hd, h, w, 5)
+    tab2 = rope.rope2d_table(hd, gh, gw, 5)
     k = torch.randn(L2, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
     nw, nb = 1 + rnd(hd, seed=79, scale=0.1), rnd(hd, seed=80, scale=0.1)
     fr = torch.cat([torch.arange(0, P), torch.arange((F - 1) * P, F * P)])

@@ -397,3 +397,48 @@ def test_hip_linear_in_enable_vram_management_module_map(fp8, monkeypatch):
     assert got.shape == want.shape and got.dtype == want.dtype
     # chained: a bf16 rounding difference of the hidden activation can flip an e4m3 quantisation step of the second layer
     assert rel_l2(got.float(), want.float()) < (3e-2 if fp8 else 6e-3)
+
+
+def test_install_leaves_no_reference_cycle_and_watches_every_packed_tensor(case_l2):
+    """(a) a model dropped WHILE installed must free its packed copy by reference counting (the rebound entries hold the
+    model weakly), (b) a change to ANY packed parameter -- not just a sampled few -- is detected at the next call, (c) install() after
+    release_reference_weights refuses instead of packing 0-element tensors."""
+    import gc
+    import weakref
+    from oracle import ref_harness
+    from oracle.ref_ops import TorchRefOps
+    from fantasy_world_amd import install
+    case = case_l2
+    model = ref_harness.build_reference_wan21(case.cfg, weights=case.weights)
+    ins = case.inputs
+    kw = dict(timestep=ins["timestep"], context=ins["context"], clip_feature=ins["clip_feature"], y=ins["y"],
+              use_gradient_checkpointing=False, camera_token=None, plucker_fea=ins["plucker_fea"],
+              plucker_context_lens=ins["plucker_context_lens"], return_prediction=False)
+    eng = install(model, ops=TorchRefOps())
+    model.joint_forward(ins["x"], **kw)
+    # (b) every packed parameter is watched: touch ONE tensor of ONE block in place
+    names = [s[0] for s in eng.weight_watch.slots]
+    assert len(names) > 100 and "IRGBlock.0.x_dit.ffn.2.bias" in names and "vggt.aggregator.frame_blocks.0.mlp.fc1.weight" in names
+    with torch.no_grad():
+        model.IRGBlock[0].x_dit.ffn[2].bias.add_(0.0)          # an in-place op bumps the version counter
+    with pytest.raises(RuntimeError, match=r"IRGBlock\.0\.x_dit\.ffn\.2\.bias"):
+        model.joint_forward(ins["x"], **kw)
+    eng = install(model, ops=TorchRefOps())                      # "install again" works and re-packs
+    model.joint_forward(ins["x"], **kw)
+    # (a) no cycle through the rebound method: with the cyclic collector OFF, dropping the model frees the engine
+    ref_engine, ref_model = weakref.ref(eng), weakref.ref(model)
+    gc.collect()
+    gc.disable()
+    try:
+        del eng, model
+        assert ref_model() is None and ref_engine() is None
+    finally:
+        gc.enable()
+    # (c) re-install after a release refuses
+    model = ref_harness.build_reference_wan21(case.cfg, weights=case.weights)
+    install(model, ops=TorchRefOps(), release_reference_weights=True)
+    kept = [n for n, p in model.named_parameters() if p.numel() > 0]
+    assert any(n.startswith("camera_condition.pose_encoder.") for n in kept)      # not packed by install(): keeps its storage
+    assert not any(n.startswith("pipe.dit.blocks.0.") for n in kept)              # packed: released
+    with pytest.raises(RuntimeError, match="released"):
+        install(model, ops=TorchRefOps())

@@ -4,7 +4,7 @@ tensors of the right shape, so every kernel runs at exactly the shapes a rank of
   --sp 1,2,4   sequence shard (L/n rows for GEMMs and norms, L rows x H/n heads for attention; parallel.py)
   --tp 2,4,8   north_star's head / FFN-column tensor parallelism (all L rows, H/n heads, 1/n of the FFN columns, replicated norms
                and fw_residual_add epilogues; tensor_parallel.py), all-reduce = no-op
-compute-only scaling bound = t(1) / t(n); communication is NOT included (DESIGN.md section 6 has the byte counts of both)."""
+compute-only scaling bound = t(1) / t(n); communication is NOT included (docs/multi_gpu.md has the byte counts of both)."""
 import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
