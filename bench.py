@@ -461,6 +461,11 @@ def main():
     if wd > 0:
         faulthandler.cancel_dump_traceback_later()
     if world > 1:
+        if shard is not None and shard.exchange_probe is not None and not shard.exchange_probe["ok"]:
+            # the probe communicator holds collectives that never completed: tearing it down could block -- the line is out, leave
+            torch.cuda.synchronize()
+            sys.stdout.flush()
+            os._exit(0)
         torch.distributed.destroy_process_group()
 
 

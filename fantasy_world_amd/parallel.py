@@ -171,26 +171,49 @@ class SequenceShard:
         self.exchange_probe = {"requested": int(requested), "ran": int(ran), "ok": bool(ok), "seconds": round(secs, 3)}
         return ran
 
-    def _probe_grouped_exchange(self, device, timeout_s):
+    def _probe_grouped_exchange(self, device, timeout_s, rounds=4, rows=512, c=256):
+        """The engine's own pattern (FusionEngine._dit_attn_begin / _dit_attn_mid), `rounds` blocks back to back on MB-sized bf16
+        messages: both q|k|v group exchanges in flight, wait for group 0, start its inverse (output) exchange while group 1 still
+        travels, wait for group 1, start its inverse exchange, wait for both outputs.  Returns False as soon as one wait does not
+        complete by the deadline (host polling of Work.is_completed(), no blocking wait), or if the data that came back is wrong."""
+        if os.environ.get("FW_SP_PROBE_FORCE_FAIL") == str(self.rank):       # test hook: this rank reports a stall
+            return False
         n = self.world
         pr = SequenceShard(self.rank, n, self.probe_group if self.probe_group is not None else self.group)
-        rows, c = 8, 4
         counts = [rows] * n
-        qkv = (torch.arange(rows * 3 * n * 2 * c, dtype=torch.float32, device=device).view(rows, 3 * n * 2 * c) + 1000.0 * self.rank)
-        pend = [pr.rows_to_heads_async(qkv, 3, counts, (0, c)), pr.rows_to_heads_async(qkv, 3, counts, (c, 2 * c))]
-        back = pr.heads_to_rows_async(torch.full((rows * n, c), float(self.rank), device=device), counts)
-        self._probe_keepalive = (pend, back, qkv)          # a stuck collective must not be destroyed under the backend
+        base = (torch.arange(rows * 3 * n * 2 * c, dtype=torch.float32, device=device) % 251).view(rows, 3 * n * 2 * c)
+        qkv = (base + self.rank).to(torch.bfloat16)
         deadline = time.monotonic() + timeout_s
-        for w in [p._work for p in pend] + [back._work]:
-            while not w.is_completed():
+        self._probe_keepalive = keep = [qkv]                # a stuck collective must not be destroyed under the backend
+
+        def done(p):
+            while not p._work.is_completed():
                 if time.monotonic() > deadline:
                     return False
                 time.sleep(0.002)
-        # completed: the data must also be what the exchange promises (rank r's rows carry 1000 r)
-        got = pend[1].wait()
-        want = torch.cat([qkv.view(rows, 3, n, 2 * c)[:, :, self.rank, c:2 * c] - 1000.0 * self.rank + 1000.0 * r for r in range(n)], dim=0)
+            return True
+        for _ in range(rounds):
+            pend = [pr.rows_to_heads_async(qkv, 3, counts, (0, c)), pr.rows_to_heads_async(qkv, 3, counts, (c, 2 * c))]
+            keep += pend
+            back = []
+            for p_ in pend:
+                if not done(p_):
+                    return False
+                got = p_.wait()                               # [rows * n, 3, c]: every rank's rows for my heads
+                back.append(pr.heads_to_rows_async(got[:, 0].contiguous(), counts))
+                keep.append(back[-1])
+            outs = []
+            for b_ in back:
+                if not done(b_):
+                    return False
+                outs.append(b_.wait())                        # [rows, n * c]: my rows, every rank's head block of q
+            # exchange followed by its inverse is the identity on q's columns of this group
+            q = qkv.view(rows, 3, n, 2 * c)[:, 0]              # [rows, n, 2c]
+            for g, o in enumerate(outs):
+                if not torch.equal(o.view(rows, n, c), q[:, :, g * c:(g + 1) * c]):
+                    return False
         self._probe_keepalive = None
-        return bool(torch.equal(got, want))
+        return True
 
     # ---- per-grid bookkeeping -----------------------------------------------------------------------------------
     def _setup(self, F, hw, n_special):
