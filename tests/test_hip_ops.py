@@ -372,6 +372,8 @@ def test_attention_all_scores_far_below_zero(attn_variant, ops, ref, parity, req
 def test_attention_full_length_properties(attn_variant, ops, parity, request, L, batch):
     """BASELINE config-2 / 4 / 5 sizes (L = 32760 / 75600 / 111600 keys, hd 128; batch 2 = the merged CFG pass): rows of softmax sum
     to 1 => V = const gives O = const, and sampled query rows match an fp32 evaluation of the same rows."""
+    if L > 32760 and attn_variant not in (0, 64, DEFAULT_ATTN_VAR):
+        pytest.skip("configs 4 / 5: the generic kernel, the ping-pong kernel and the default choice (the other variants at L = 32 760)")
     heads, hd = 2, 128
     g = torch.Generator(device="cuda").manual_seed(0)
     q = torch.randn(batch * L, heads * hd, device="cuda", generator=g).to(torch.bfloat16)
