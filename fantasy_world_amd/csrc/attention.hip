@@ -38,7 +38,7 @@ struct AttnArgs {
     // and its softmax shifts (fp32, [bh][qb][run][256 rows][HD + 2]) and attention_combine_kernel merges the runs.
     float* part;
     int nsplit, tiles_per_split;
-    int nofast;         // A/B (FW_ATTN_VAR bit 10): 1 = the tile requests of the hot loop by the general path (clamp + ragged fix-up + 64-bit multiply)
+    int nofast;         // A/B (FW_ATTN_VAR bit 10): 1 = tile requests in pointer form (64-bit multiply-add + ragged-row fix-up), not by descriptor
     int prio;           // experiment (FW_ATTN_VAR bits 8-9): 1 = s_setprio 1 for waves 4..7, 2 = for waves 0..3, before the tile loop;
                         // measured +-0 on every shape (profiles/r03/microbench_attention_static_priority.txt), default 0
 };
@@ -397,9 +397,21 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
     }
     const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
+    // (round 4: requests by SGPR descriptor + scalar tile offset, as in attention_sp_kernel -- see the comment there)
+    const size_t kbytes = (size_t)p.Lk * (size_t)p.ldk * 2, vbytes = (size_t)HD * (size_t)p.lkp * 2;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(unsigned)(kbytes > 0xffffffffull ? 0xffffffffull : kbytes), 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)(vbytes > 0xffffffffull ? 0xffffffffull : vbytes), 0x00020000);
+    const bool buf_ok = kbytes < 0xffffffffull && vbytes < 0xffffffffull && !p.nofast;
     auto issue_k = [&](int t) {
-        const char* kt = Kp + (size_t)t * k_tile_stride;
         char* k_lds = smem + (t & (ARING - 1)) * K_TILE_BYTES;
+        if (buf_ok) {
+            const unsigned so = (unsigned)t * (unsigned)k_tile_stride;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (kvalid[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, FW_LDS_PTR(k_lds + (wave + 8 * i) * 1024), 16, (int)koff[i], (int)so, 0, 0);
+            return;
+        }
+        const char* kt = Kp + (size_t)t * k_tile_stride;
         const bool last = ragged && t == nt - 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -413,8 +425,15 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         }
     };
     auto issue_v = [&](int t) {
-        const char* vt = Vp + (size_t)t * (KVB * 2);
         char* v_lds = smem + V_BASE + (t & (ARING - 1)) * VT_TILE_BYTES;
+        if (buf_ok) {
+            const unsigned so = (unsigned)t * (KVB * 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (lane < VLANES) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, FW_LDS_PTR(v_lds + (wave * 2 + i) * (VROWS * 128)), 16, (int)voff[i], (int)so, 0, 0);
+            return;
+        }
+        const char* vt = Vp + (size_t)t * (KVB * 2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave * 2 + i) * (VROWS * 128));
@@ -696,6 +715,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     // tile (hd 128) on LDS addresses (16 v_add_u32, 9 v_or_b32, 2 v_lshl_add) -- and VALU cycles ADD to the matrix cycles on this
     // SIMD (docs/kernels.md, "attention: the cap").
     constexpr bool UNR = (VAR & 64) != 0;
+    constexpr bool BUF = UNR && (VAR & 256) == 0;   // tile requests by SGPR descriptor + scalar tile offset (below); bit 8: pointer form
     constexpr int NS = (VAR & 2) ? 2 : 1;     // 32-row sub-blocks per wave: 2 = one wave per SIMD owning 64 query rows
     constexpr int NW = 8 / NS;                // waves per work-group (256 query rows either way)
     constexpr int NP = 16 / NW;               // 1 KiB K pieces / Vt pieces each wave requests per tile
@@ -770,9 +790,29 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
     }
     const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
+    // Round 4: the requests go through buffer_load ... lds with an SGPR descriptor over this (batch, head, run)'s K rows / Vt rows: the
+    // per-lane part of the address is the 32-bit offset register, the tile's byte offset is the SCALAR offset (one s_mul_i32), and the
+    // rows of a ragged last tile past the last key are out of the descriptor's range (zeros; their scores are masked) -- instead of a
+    // 64-bit multiply-add per request and the ragged-row selects (25 SALU + 6 VALU per tile and wave in the round-3 ISA, on a SIMD
+    // whose issue port the ~155 non-MFMA instructions per 32 MFMAs already fill).  The pointer form stays, as its own instantiation, for
+    // views of 4 GiB or more (and as the A/B arm, FW_ATTN_VAR bit 10).
+    const size_t kbytes = (size_t)(p.Lk - key0) * (size_t)p.ldk * 2, vbytes = ((size_t)HD * (size_t)p.lkp - (size_t)key0) * 2;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(unsigned)(kbytes > 0xffffffffull ? 0xffffffffull : kbytes), 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)(vbytes > 0xffffffffull ? 0xffffffffull : vbytes), 0x00020000);
+    // (the launcher sends views of 4 GiB or more, and FW_ATTN_VAR bit 10, to the pointer-form instantiation: both forms in ONE kernel
+    //  cost hd 128 436 B of scratch)
     auto issue_k = [&](int t, int slot) __attribute__((always_inline)) {
-        const char* kt = Kp + (size_t)t * k_tile_stride;
         char* k_lds = smem + (slot & (ARING - 1)) * K_TILE_BYTES;
+        if constexpr (BUF) {
+            // (the builtin's offset operands are `int`: handed an `unsigned` inside this generic lambda hipcc drops the HOST stub of
+            //  every instantiation of the kernel without a diagnostic and the library fails to load)
+            const unsigned so = (unsigned)t * (unsigned)k_tile_stride;
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (kvalid[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, FW_LDS_PTR(k_lds + (wave + NW * i) * 1024), 16, (int)koff[i], (int)so, 0, 0);
+            return;
+        }
+        const char* kt = Kp + (size_t)t * k_tile_stride;
         const bool last = ragged && t == nt - 1;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -786,38 +826,19 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         }
     };
     auto issue_v = [&](int t, int slot) __attribute__((always_inline)) {
-        const char* vt = Vp + (size_t)t * (KVB * 2);
         char* v_lds = smem + V_BASE + (slot & (ARING - 1)) * VT_TILE_BYTES;
+        if constexpr (BUF) {
+            const unsigned so = (unsigned)t * (KVB * 2);
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (lane < VLANES) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, FW_LDS_PTR(v_lds + (wave + NW * i) * (VROWS * 128)), 16, (int)voff[i], (int)so, 0, 0);
+            return;
+        }
+        const char* vt = Vp + (size_t)t * (KVB * 2);
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             if (lane < VLANES) FW_GLDS16(vt + voff[i], v_lds + (wave + NW * i) * (VROWS * 128));
     };
-    // Round 4: the same requests for tiles that are known to exist and not to be the last one (no clamp, no ragged-row fix-up), through
-    // buffer_load ... lds with an SGPR descriptor: the per-lane part of the address is the 32-bit offset register the general path
-    // already holds, the tile's byte offset is the SCALAR offset.  The hot loop then carries two scalar adds per 4 tiles instead of a
-    // 64-bit multiply, a clamp and the ragged-tile selects per request (25 SALU + 6 VALU per tile and wave in the round-3 ISA -- on a
-    // SIMD whose issue port the 155 non-MFMA instructions per 32 MFMAs already fill).
-    const size_t kbytes = (size_t)(p.Lk - key0) * (size_t)p.ldk * 2, vbytes = (size_t)HD * (size_t)p.lkp * 2;
-    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(unsigned)(kbytes > 0xffffffffull ? 0xffffffffull : kbytes), 0x00020000);
-    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)(vbytes > 0xffffffffull ? 0xffffffffull : vbytes), 0x00020000);
-    // (the builtin's offset operands are `int`: handed an `unsigned` inside these generic lambdas, hipcc drops the HOST stub of every
-    //  instantiation of this kernel without a diagnostic -- the library then fails to load with an undefined __device_stub__ symbol)
-    auto issue_k_fast = [&](unsigned ksoff, int slot) __attribute__((always_inline)) {
-        char* k_lds = smem + (slot & (ARING - 1)) * K_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-            if (kvalid[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, FW_LDS_PTR(k_lds + (wave + NW * i) * 1024), 16, (int)koff[i], (int)ksoff, 0, 0);
-    };
-    auto issue_v_fast = [&](unsigned vsoff, int slot) __attribute__((always_inline)) {
-        char* v_lds = smem + V_BASE + (slot & (ARING - 1)) * VT_TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-            if (lane < VLANES) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, FW_LDS_PTR(v_lds + (wave + NW * i) * (VROWS * 128)), 16, (int)voff[i], (int)vsoff, 0, 0);
-    };
-    // (only when every tile offset fits the 32-bit scalar offset: the K rows of one (batch, head) view span < 4 GiB)
-    const bool fast_ok = kbytes < 0xffffffffull && vbytes < 0xffffffffull && !p.nofast;
-    unsigned kfast = 0, vfast = 0;            // byte offsets of K tile (t + 3) / Vt tile (t + 2) of the unrolled iteration that starts at t
-
     int kcoff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kcoff[ks] = fi * 256 + (((2 * ks + hi) ^ (fi & 15)) << 4);
@@ -957,20 +978,13 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     // one 64-key tile.  The ring slot of K(t+3) held K(t-1) and that of Vt(t+2) held Vt(t-2), both dead; near the end the
     // requests are clamped to the last tile (they land in slots nobody reads) so the wait count stays a constant.
     using SR = std::integral_constant<int, -1>;
-    auto tile = [&](int t, auto slot_tag, auto last_tag, auto fast_tag) __attribute__((always_inline)) {
+    auto tile = [&](int t, auto slot_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
-        constexpr bool FAST = decltype(fast_tag)::value;      // unrolled loop far from the end: requests by running scalar tile offsets
-        constexpr int SLT = decltype(slot_tag)::value < 0 ? 0 : decltype(slot_tag)::value;
         using NotLast = std::integral_constant<bool, !LAST>;
         half(sA, sB, t, slot_tag, H0{}, T_{}, NotLast{}, last_tag);
         if (!LAST && !AB_NODMA) {
-            if (FAST) {
-                issue_k_fast(kfast + (unsigned)SLT * (unsigned)k_tile_stride, (SLT + 3) & (ARING - 1));
-                issue_v_fast(vfast + (unsigned)SLT * (KVB * 2), (SLT + 2) & (ARING - 1));
-            } else {
-                issue_k(min(t + 3, nt - 1), t + 3);
-                issue_v(min(t + 2, nt - 1), t + 2);
-            }
+            issue_k(min(t + 3, nt - 1), t + 3);
+            issue_v(min(t + 2, nt - 1), t + 2);
         }
         half(sB, sA, t, slot_tag, H1{}, NotLast{}, NotLast{}, last_tag);
         if (!LAST && !AB_NODMA) {
@@ -1052,38 +1066,25 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
             half(sB, sA, t, SR{}, H1{}, T_{}, T_{}, F_{});
             ++t;
         }
-        tile(t, SR{}, T_{}, F_{});
+        tile(t, SR{}, T_{});
     } else if (UNR) {
         int t = 0;
         static_assert(ARING == 4, "the bodies below are unrolled by hand over ring slots 0..3");
-        // fast loop: every request of the iteration (K tiles t+3 .. t+6, Vt tiles t+2 .. t+5) is an existing tile that is not the last
-        // (hd 128 only: at hd 64 the second copy of the loop tips the register allocator over the 256-VGPR edge: 104 B of scratch)
-        kfast = 3u * (unsigned)k_tile_stride;
-        vfast = 2u * (KVB * 2);
-#pragma unroll 1
-        for (; HD == 128 && fast_ok && t + 8 <= nt; t += ARING) {
-            tile(t, std::integral_constant<int, 0>{}, F_{}, T_{});
-            tile(t + 1, std::integral_constant<int, 1>{}, F_{}, T_{});
-            tile(t + 2, std::integral_constant<int, 2>{}, F_{}, T_{});
-            tile(t + 3, std::integral_constant<int, 3>{}, F_{}, T_{});
-            kfast += ARING * (unsigned)k_tile_stride;
-            vfast += ARING * (KVB * 2);
-        }
 #pragma unroll 1
         for (; t + ARING <= nt - 1; t += ARING) {       // t is a multiple of the ring depth here: slots 0, 1, 2, 3
-            tile(t, std::integral_constant<int, 0>{}, F_{}, F_{});
-            tile(t + 1, std::integral_constant<int, 1>{}, F_{}, F_{});
-            tile(t + 2, std::integral_constant<int, 2>{}, F_{}, F_{});
-            tile(t + 3, std::integral_constant<int, 3>{}, F_{}, F_{});
+            tile(t, std::integral_constant<int, 0>{}, F_{});
+            tile(t + 1, std::integral_constant<int, 1>{}, F_{});
+            tile(t + 2, std::integral_constant<int, 2>{}, F_{});
+            tile(t + 3, std::integral_constant<int, 3>{}, F_{});
         }
 #pragma unroll 1
-        for (; t < nt - 1; ++t) tile(t, SR{}, F_{}, F_{});
-        tile(nt - 1, SR{}, T_{}, F_{});
+        for (; t < nt - 1; ++t) tile(t, SR{}, F_{});
+        tile(nt - 1, SR{}, T_{});
     } else {
         if (nt > 1) {
-            for (int t = 0; t < nt - 1; ++t) tile(t, SR{}, F_{}, F_{});
+            for (int t = 0; t < nt - 1; ++t) tile(t, SR{}, F_{});
         }
-        tile(nt - 1, SR{}, T_{}, F_{});
+        tile(nt - 1, SR{}, T_{});
     }
     if (NS == 2) fw_mfma_drain();
 
@@ -1344,7 +1345,7 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     p.nqb = (Lq + QB - 1) / QB;
     p.part = nullptr; p.nsplit = 1; p.tiles_per_split = 0;
     p.prio = (fw_get_option(FW_OPT_ATTN_VAR) >> 8) & 3;
-    p.nofast = (fw_get_option(FW_OPT_ATTN_VAR) >> 10) & 1;      // A/B: 1024 = without the round-4 fast request loop
+    p.nofast = (fw_get_option(FW_OPT_ATTN_VAR) >> 10) & 1;      // A/B: 1024 = tile requests in the round-3 pointer form
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_bf16: grid too large"); return FW_E_BADARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -1391,7 +1392,10 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     do { if (head_dim == 128) FW_ATTN_SP(128, V); else if (head_dim == 96) FW_ATTN_SP(96, V); else FW_ATTN_SP(64, V); } while (0)
 #define FW_ATTN_SP_HD_UNR(V) do { if (head_dim == 128) FW_ATTN_SP(128, V); else FW_ATTN_SP(64, V); } while (0)
         if (var & 64) {                                                                         // tile loop unrolled by the ring depth
-            if (var & 4) FW_ATTN_SP_HD_UNR(64);               // 196: without the sched_group_barrier pins
+            // (requests by descriptor need every byte offset of the (batch, head) view in 32 bits; else, and for the A/B, pointer form)
+            const bool ptr_form = p.nofast || (size_t)Lk * (size_t)ldk * 2 >= 0xffffffffull || (size_t)head_dim * (size_t)Lk_pad * 2 >= 0xffffffffull;
+            if (ptr_form) { if (head_dim == 128) FW_ATTN_SP(128, 321); else FW_ATTN_SP(64, 320); }
+            else if (var & 4) FW_ATTN_SP_HD_UNR(64);          // 196: without the sched_group_barrier pins
             else if (var & 2) FW_ATTN_SP_HD_UNR(67);
             else FW_ATTN_SP_HD_UNR(65);
         }
