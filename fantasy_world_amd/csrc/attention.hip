@@ -338,6 +338,7 @@ template <int HD, int VAR>
 __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
     constexpr bool DMA_QK = (VAR & 1) != 0;
     constexpr bool TIMING = (VAR & 2) != 0;
+    constexpr bool BUF = (VAR & 8) == 0;       // tile requests by SGPR descriptor (below); bit 3: the round-3 pointer form
     constexpr bool NOPIN = (VAR & 4) != 0;     // experiment: let LLVM sink the softmax next to the PV MFMAs (intra-wave interleave)    // measurement build: s_memtime at the segment boundaries of one tile
     constexpr int KS = HD / 16, DB = HD / 32, NCH = HD / 8, NFR = HD / 8;
     constexpr int VT_TILE_BYTES = HD * 128;
@@ -397,14 +398,17 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         voff[i] = (unsigned)(d * (int)p.lkp + chunk * 8) * 2u;
     }
     const size_t k_tile_stride = (size_t)KVB * (size_t)p.ldk * 2;
-    // (round 4: requests by SGPR descriptor + scalar tile offset, as in attention_sp_kernel -- see the comment there)
+    // (round 4: requests by SGPR descriptor + scalar tile offset, as in attention_sp_kernel -- see the comment there.  A tile past the
+    //  last one is then a legal request -- rows out of the descriptor's range return zeros, into a ring slot nobody reads any more --
+    //  so EVERY tile issues its 4 requests and the counted waits are the same constants from the first tile to the last: the three-way
+    //  "steady / draining" choice in front of both barriers of a tile and the t + 4 < nt tests, ~35 scalar instructions and ~10
+    //  branches of the ~100 per tile in the round-3 ISA, are gone.  Views of 4 GiB or more: the pointer-form instantiation, VAR bit 3.)
     const size_t kbytes = (size_t)p.Lk * (size_t)p.ldk * 2, vbytes = (size_t)HD * (size_t)p.lkp * 2;
     const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(unsigned)(kbytes > 0xffffffffull ? 0xffffffffull : kbytes), 0x00020000);
     const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)(vbytes > 0xffffffffull ? 0xffffffffull : vbytes), 0x00020000);
-    const bool buf_ok = kbytes < 0xffffffffull && vbytes < 0xffffffffull && !p.nofast;
     auto issue_k = [&](int t) {
         char* k_lds = smem + (t & (ARING - 1)) * K_TILE_BYTES;
-        if (buf_ok) {
+        if constexpr (BUF) {
             const unsigned so = (unsigned)t * (unsigned)k_tile_stride;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
     };
     auto issue_v = [&](int t) {
         char* v_lds = smem + V_BASE + (t & (ARING - 1)) * VT_TILE_BYTES;
-        if (buf_ok) {
+        if constexpr (BUF) {
             const unsigned so = (unsigned)t * (KVB * 2);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -462,8 +466,8 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
     issue_k(0);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        if (j + 1 < nt) issue_k(j + 1);
-        if (j < nt) issue_v(j);
+        if (BUF || j + 1 < nt) issue_k(j + 1);
+        if (BUF || j < nt) issue_v(j);
     }
     fw_await_vm<0>();
     FW_ABARRIER();
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         constexpr bool has1 = decltype(has1_tag)::value;
         const int s_cur = SL >= 0 ? SL : (t & (ARING - 1));
         const int s_nxt = SL >= 0 ? ((SL + 1) & (ARING - 1)) : ((t + 1) & (ARING - 1));
-        const bool steady = t + 4 < nt;
+        const bool steady = BUF || t + 4 < nt;
         // ------------------------------------------------------------ V(t): Vt fragments -> registers, softmax
         FW_TS(0);
         {
@@ -561,8 +565,8 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
         FW_TS(3);
         // ------------------------------------------------------------ MM(t): PV(t), K(t+1) fragments, QK^T(t+1)
         if (!DMA_QK) {
-            if (t + 4 < nt) issue_k(t + 4);
-            if (t + 3 < nt) issue_v(t + 3);
+            if (BUF || t + 4 < nt) issue_k(t + 4);
+            if (BUF || t + 3 < nt) issue_v(t + 3);
         }
         const char* kb = smem + s_nxt * K_TILE_BYTES;
         const char* vb2 = smem + s_cur * VT_TILE_BYTES;
@@ -608,8 +612,8 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
                     }
                 }
                 if (DMA_QK) {
-                    if (ks == KS / 2 && t + 4 < nt) issue_k(t + 4);
-                    if (ks == KS / 2 + 1 && t + 3 < nt) issue_v(t + 3);
+                    if (ks == KS / 2 && (BUF || t + 4 < nt)) issue_k(t + 4);
+                    if (ks == KS / 2 + 1 && (BUF || t + 3 < nt)) issue_v(t + 3);
                 }
             }
             // pin the issue order: MFMA, ds_read, MFMA, ds_read, ...
@@ -635,9 +639,12 @@ __global__ __launch_bounds__(512, 2) void attention_pp3_kernel(AttnArgs p) {
     //  copies cost more than the 7 address instructions per tile they save.  slot_tag stays run time.)
     {
         using SRT = std::integral_constant<int, -1>;
+        // (round 4: one straight-line copy of the loop per wave group, the group's counted waits compile-time constants -- 4 branches
+        //  and 8 scalar instructions per tile fewer, 32 VGPRs more: 4.026 vs 4.002 ms at hd 96, no gain; one copy stays.)
         for (; t < nt - 1; ++t) tile(SRT{}, std::true_type{});
         tile(SRT{}, std::false_type{});
     }
+    if (BUF) fw_await_vm<0>();      // the requests past the last tile still write this work-group's LDS: drain them before it is released
     if (grp == 0) FW_ABARRIER();
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -1305,6 +1312,12 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
 // two separate forwards do, or the pair is no longer bit-identical to them (round-2 advisor finding: target = 256 / (heads *
 // batch) gave 16 runs at batch 1 and 8 at batch 2 for the VGGT global attention at L2 = 32865).  The criterion is the
 // per-sample grid: the tail work-groups of ONE sample would open a new round of the 256 CUs.
+// Requests by descriptor carry byte offsets in 32 bits (lane offset + scalar tile offset, tiles up to 4 past the last one).
+static bool attn_view_needs_pointers(int Lk, int64_t ldk, int head_dim, int64_t Lk_pad) {
+    const size_t lim = 0xffffffffull;
+    return ((size_t)Lk + 5 * KVB) * (size_t)ldk * 2 >= lim || ((size_t)head_dim * (size_t)Lk_pad + 5 * KVB) * 2 >= lim;
+}
+
 static bool attn_split_plan(int heads, int Lq, int Lk, int* nsplit, int* tps) {
     const int tail = Lq % QB, nqb_full = Lq / QB;
     const int nt = (Lk + KVB - 1) / KVB;
@@ -1393,7 +1406,7 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
 #define FW_ATTN_SP_HD_UNR(V) do { if (head_dim == 128) FW_ATTN_SP(128, V); else FW_ATTN_SP(64, V); } while (0)
         if (var & 64) {                                                                         // tile loop unrolled by the ring depth
             // (requests by descriptor need every byte offset of the (batch, head) view in 32 bits; else, and for the A/B, pointer form)
-            const bool ptr_form = p.nofast || (size_t)Lk * (size_t)ldk * 2 >= 0xffffffffull || (size_t)head_dim * (size_t)Lk_pad * 2 >= 0xffffffffull;
+            const bool ptr_form = p.nofast || attn_view_needs_pointers(Lk, ldk, head_dim, Lk_pad);
             if (ptr_form) { if (head_dim == 128) FW_ATTN_SP(128, 321); else FW_ATTN_SP(64, 320); }
             else if (var & 4) FW_ATTN_SP_HD_UNR(64);          // 196: without the sched_group_barrier pins
             else if (var & 2) FW_ATTN_SP_HD_UNR(67);
@@ -1405,7 +1418,9 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
     if (prescaled && var >= 64) {
         // two-segment ping-pong on log2-domain scores; bit 1: TIMING build (tools/attn_timeline.py)
 #define FW_ATTN_PP3(HDV, V) hipLaunchKernelGGL((attention_pp3_kernel<HDV, V>), dim3((unsigned)nwg), dim3(512), 0, st, p)
-        if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
+        const bool ptr_form = p.nofast || attn_view_needs_pointers(Lk, ldk, head_dim, Lk_pad);
+        if (ptr_form) { if (head_dim == 128) FW_ATTN_PP3(128, 8); else if (head_dim == 96) FW_ATTN_PP3(96, 8); else FW_ATTN_PP3(64, 8); }
+        else if ((var & 3) == 2) { if (head_dim == 128) FW_ATTN_PP3(128, 2); else if (head_dim == 96) FW_ATTN_PP3(96, 2); else FW_ATTN_PP3(64, 2); }
         else { if (head_dim == 128) FW_ATTN_PP3(128, 0); else if (head_dim == 96) FW_ATTN_PP3(96, 0); else FW_ATTN_PP3(64, 0); }
         return (int)hipGetLastError();
     }
