@@ -333,6 +333,27 @@ def test_attention_strided_qkv_and_accumulate(attn_variant, ops, ref, parity, re
     parity.check(f"op/{request.node.name}/1", rel_l2(got.float(), want2), 5e-3)
 
 
+@pytest.mark.parametrize("heads,hd,batch,Lq,Lk", [(3, 128, 1, 300, 333), (5, 128, 2, 520, 257), (12, 96, 1, 290, 305), (4, 96, 2, 100, 64),
+                                                   (16, 64, 3, 133, 133), (2, 64, 1, 700, 1), (2, 128, 1, 64, 2048)])
+def test_attention_descriptor_requests_return_the_bits_of_the_pointer_form(ops, heads, hd, batch, Lq, Lk):
+    """Round 4: the production kernels request their K / Vt tiles through an SGPR buffer descriptor (rows past the last key are out of
+    its range: zeros, masked anyway; the ping-pong kernel also requests tiles past the last one); FW_ATTN_VAR bit 10 selects the
+    round-3 pointer form (clamped rows, conditional requests).  Same bits -- ragged last tiles, one-key sequences, batches and
+    k | v column slices of one buffer included."""
+    D = heads * hd
+    q = bf(rnd(batch * Lq, D, seed=41) * ops.q_scale(hd)).cuda()
+    kv = bf(rnd(batch * Lk, 2 * D, seed=42)).cuda()
+    outs = []
+    try:
+        for var in (DEFAULT_ATTN_VAR, DEFAULT_ATTN_VAR + 1024):
+            ops.set_option("attn_var", var)
+            outs.append(ops.attention(q, kv[:, :D], kv[:, D:], heads, hd, batch=batch, q_prescaled=True).clone())
+    finally:
+        ops.set_option("attn_var", DEFAULT_ATTN_VAR)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0].float()).all()
+
+
 @pytest.mark.parametrize("gain", [3.0, 40.0])
 def test_attention_large_score_spike(attn_variant, ops, ref, gain, parity, request):
     """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence (gain 40: the spike is
