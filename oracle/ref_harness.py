@@ -390,3 +390,82 @@ def run_reference_heads(vggt, output_list, S, ph, pw, n_layers, patch_start_idx=
     with torch.no_grad(), warnings.catch_warnings():
         warnings.simplefilter("ignore")
         return vggt._head_predction(images, patch_start_idx, agg)
+
+
+# ---- checker-side helpers for the GPU box (the module tree stays the reference's own) -------------------------------------------
+FP8_SITES = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v", "cross_attn.o",
+             "ffn.0", "ffn.2")
+
+
+class Fp8LinearByDefinition(nn.Module):
+    """Stand-in for AutoWrappedLinear(computation_dtype=float8_e4m3fn) around ONE nn.Linear of the reference
+    (diffsynth_wan22/vram_management/layers.py:113-166): its forward is `AutoWrappedLinear.fp8_linear` (layers.py:115-151) written by
+    its definition (oracle/fw_oracle.py:fp8_linear -- bit-identical to the real torch._scaled_mm call,
+    tests/test_reference_on_gpu.py::test_fp8_linear_against_the_real_scaled_mm; the real call refuses fp32 activations)."""
+
+    def __init__(self, lin):
+        super().__init__()
+        self.weight, self.bias = lin.weight, lin.bias
+
+    def forward(self, x, *a, **k):
+        from oracle import fw_oracle
+        return fw_oracle.fp8_linear(x, self.weight, self.bias)
+
+
+def swap_fp8_linears(model, start_index):
+    """Swap the nn.Linear modules `enable_vram_management(module_map={nn.Linear: AutoWrappedLinear}, computation_dtype=float8_e4m3fn)`
+    would wrap inside every DiT block (FP8_SITES) for Fp8LinearByDefinition.  Returns the number of modules swapped."""
+    blocks = [model.pipe.dit.blocks[b] for b in range(start_index)] + [ib.x_dit for ib in model.IRGBlock]
+    n = 0
+    for blk in blocks:
+        for site in FP8_SITES:
+            owner_name, leaf = site.split(".")
+            owner = getattr(blk, owner_name)
+            lin = owner[int(leaf)] if leaf.isdigit() else getattr(owner, leaf)
+            assert isinstance(lin, nn.Linear), (site, type(lin))
+            if leaf.isdigit():
+                owner[int(leaf)] = Fp8LinearByDefinition(lin)
+            else:
+                setattr(owner, leaf, Fp8LinearByDefinition(lin))
+            n += 1
+    return n
+
+
+class sdpa_by_head_chunks:
+    """Context manager: while active, `torch.nn.functional.scaled_dot_product_attention` -- the call the reference's attention sites
+    make (wan_video_dit.py:44-48, vggt/layers/attention.py:61, fusion/layer/block.py:598-605) -- runs over chunks of heads whenever
+    the fp32 score matrix of all heads together would exceed `limit_bytes`.  Attention heads are independent, so the result is the
+    one the unchunked call defines; what changes is the checker's peak memory (4.3 GB per head at L = 32 760 instead of 172 GB for
+    40 heads if the math backend materialises the scores): VERDICT r04 "weak 3" -- the benchmarked-size pin must not depend on an
+    allocator's luck.  Test infrastructure: the module tree and its code stay unmodified."""
+
+    def __init__(self, limit_bytes=24 << 30):
+        self.limit = int(limit_bytes)
+        self.calls = self.chunked = 0
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._F, self._orig = F, F.scaled_dot_product_attention
+        orig = self._orig
+
+        def sdpa(q, k, v, *a, **kw):
+            self.calls += 1
+            if q.dim() not in (3, 4) or a or kw.get("attn_mask") is not None:
+                return orig(q, k, v, *a, **kw)
+            # [b, heads, L, hd] (DiT, VGGT) or [b * heads, L, hd] (bicross, block.py:560-566): the head axis is dim -3
+            ax = q.dim() - 3
+            h, lq, lk = q.shape[ax], q.shape[-2], k.shape[-2]
+            per_head = (q.numel() // (h * lq * q.shape[-1])) * lq * lk * 4
+            if h == 1 or per_head * h <= self.limit:
+                return orig(q, k, v, *a, **kw)
+            step = max(1, self.limit // per_head)
+            self.chunked += 1
+            return torch.cat([orig(q.narrow(ax, i, min(step, h - i)), k.narrow(ax, i, min(step, h - i)),
+                                   v.narrow(ax, i, min(step, h - i)), **kw) for i in range(0, h, step)], dim=ax)
+
+        F.scaled_dot_product_attention = sdpa
+        return self
+
+    def __exit__(self, *exc):
+        self._F.scaled_dot_product_attention = self._orig
+        return False

@@ -119,7 +119,7 @@ class TorchRefOps:
         elif norm == "ln_head":
             v = F.layer_norm(v.view(rows, heads, hd), (hd,), norm_w, norm_b, eps).reshape(rows, heads * hd)
         if rope not in (None, "none"):
-            tab = table[torch.arange(rows) % table.shape[0]]          # [rows, hd/2, 2]
+            tab = table.to(x.device)[torch.arange(rows, device=x.device) % table.shape[0]]          # [rows, hd/2, 2]
             cs, sn = tab[..., 0].unsqueeze(1), tab[..., 1].unsqueeze(1)  # [rows, 1, hd/2]
             vh = v.view(rows, heads, hd)
             if rope == "interleaved":
@@ -161,7 +161,7 @@ class TorchRefOps:
         if dev_params is not None:
             cfg_scale, dsigma = float(dev_params[0]), float(dev_params[1])
         noise_pred = neg + cfg_scale * (pos - neg)
-        r = latents + noise_pred * torch.tensor(dsigma, dtype=torch.float32)
+        r = latents + noise_pred * torch.tensor(dsigma, dtype=torch.float32, device=latents.device)
         if out is not None:
             out.copy_(r)
             return out
@@ -195,7 +195,7 @@ class TorchRefOps:
     def sinusoid(self, t, dim):
         half = dim // 2
         pos = t.reshape(-1)[:1].to(torch.float64)
-        freq = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half)
+        freq = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64, device=pos.device) / half)
         a = pos * freq
         return torch.cat([torch.cos(a), torch.sin(a)]).to(torch.float32)
 
@@ -205,7 +205,7 @@ class TorchRefOps:
         _, C, F_, H2, W2 = xy.shape
         h, w = H2 // 2, W2 // 2
         p = xy[0].view(C, F_, h, 2, w, 2).permute(1, 2, 4, 0, 3, 5).reshape(F_ * h * w, C * 4)
-        out = torch.zeros(F_ * h * w, kpad)
+        out = torch.zeros(F_ * h * w, kpad, device=xy.device)
         out[:, : C * 4] = p
         return self._r(out)
 

@@ -24,37 +24,6 @@ from oracle import ref_locate
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_locate.available(), reason="reference not mounted / staged")]
 
 DEV = "cuda:0"
-FP8_SITES = ("self_attn.q", "self_attn.k", "self_attn.v", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v", "cross_attn.o",
-             "ffn.0", "ffn.2")
-
-
-class _Fp8LinearByDefinition(torch.nn.Module):
-    """Stand-in for AutoWrappedLinear(computation_dtype=float8_e4m3fn) around one nn.Linear of the reference."""
-
-    def __init__(self, lin):
-        super().__init__()
-        self.weight, self.bias = lin.weight, lin.bias
-
-    def forward(self, x, *a, **k):
-        from oracle import fw_oracle
-        return fw_oracle.fp8_linear(x, self.weight, self.bias)
-
-
-def _swap_fp8(model, cfg):
-    blocks = [model.pipe.dit.blocks[b] for b in range(cfg.start_index)] + [ib.x_dit for ib in model.IRGBlock]
-    n = 0
-    for blk in blocks:
-        for site in FP8_SITES:
-            owner_name, leaf = site.split(".")
-            owner = getattr(blk, owner_name)
-            lin = owner[int(leaf)] if leaf.isdigit() else getattr(owner, leaf)
-            assert isinstance(lin, torch.nn.Linear), (site, type(lin))
-            if leaf.isdigit():
-                owner[int(leaf)] = _Fp8LinearByDefinition(lin)
-            else:
-                setattr(owner, leaf, _Fp8LinearByDefinition(lin))
-            n += 1
-    return n
 
 
 def test_config5_grid_against_the_reference(parity):
@@ -94,7 +63,7 @@ def test_config5_grid_against_the_reference(parity):
     del eng, params
     torch.cuda.empty_cache()
 
-    assert _swap_fp8(model, cfg) == 2 * len(FP8_SITES)
+    assert ref_harness.swap_fp8_linears(model, cfg.start_index) == 2 * len(ref_harness.FP8_SITES)
     with torch.no_grad():
         want8, _ = model.joint_forward(ins["x"], **kw)                         # the reference with the fp8 linear in those modules
     torch.cuda.synchronize()

@@ -14,8 +14,16 @@ Then install() (B1) and the same calls on the HIP path; compared: noise_pred, bo
 
 Grids: a small one (seconds), and one whose token count (L = 8190) puts every GEMM and attention on the kernels the benchmark runs
 (256 x 256 ping-pong GEMM with the M-tail peel, 64 query blocks per head, split-KV tails); for Wan2.1 -- the model bench.py times --
-additionally ONE forward at the headline grid itself (L = 32 760; the reference's fp32 attention fits the 288 GB device next to 74 GB of
-fp32 weights and 36 GB of packed ones: measured 2.97e-3, profiles/r04/parity.json).
+additionally ONE forward at the headline grid itself (L = 32 760; measured 2.97e-3, profiles/r04/parity.json).  Round 5: the headline
+leg runs for BOTH flavours by default, the checker's attention runs head chunk by head chunk (oracle/ref_harness.py:sdpa_by_head_chunks --
+24 GB of fp32 scores at a time instead of 172 GB; heads are independent, the module tree stays unmodified), and a checker that still
+does not fit FAILS the test (FW_FULL_DEPTH_HEADLINE_OPTIONAL=1 turns that into a recorded note; FW_FULL_DEPTH_HEADLINE=0 skips the leg;
+FW_FULL_DEPTH_CONFIG4=1 adds the Wan2.2 81f x 720p grid, L = 75 600, minutes of fp32 reference time).
+
+Round 5 also: (i) the bf16-rounding YARDSTICK at this depth -- the engine's own host code on torch ops with activations rounded to bf16
+where the HIP path stores bf16 (oracle/ref_ops.py:TorchRefOps(emulate_bf16=True)) against the same fp32 reference, 40 / 24 / 24 blocks,
+L = 8190 -- recorded next to the HIP path's numbers (the "floor" docs/parity.md quotes was an 8-block CPU number until now);
+(ii) test_full_depth_fp8_*: BASELINE configs[4]'s arithmetic ("fp8 attention + FFN") at the benchmarked depth.
 """
 import os
 
@@ -85,9 +93,11 @@ def _reference_forward(model, cfg, ins, return_prediction):
                 cap["x"][b] = out[0][0].float().clone()
                 cap["tok"][b] = out[1][0].float().clone()
             hooks.append(model.IRGBlock[b - cfg.start_index].register_forward_hook(hook))
+    from oracle import ref_harness
     try:
-        with torch.no_grad():
+        with torch.no_grad(), ref_harness.sdpa_by_head_chunks() as chunks:
             out, pred = model.joint_forward(ins["x"], **_kwargs(cfg, ins, return_prediction))
+        assert chunks.calls > 0                 # the reference's attention sites did go through the call that is chunked
     finally:
         for h in hooks:
             h.remove()
@@ -131,9 +141,35 @@ def _compare(tag, parity, want, got, cfg, with_pred):
     print(tag, {k: f"{v:.2e}" for k, v in rows.items()})
     # a broken adapter boundary shows as a jump between blocks 24 and 25, far above the depth curve's slope
     assert rows["x@25"] < rows["x@24"] + 2.5 * rows["x@15"] + 1e-3, rows
+    return rows
 
 
 GRIDS = {"small_f3_12x16": (3, 12, 16), "production_kernels_f21_30x52": (21, 30, 52)}
+YARDSTICK_GRID = "production_kernels_f21_30x52"
+
+
+def _grids(flavour):
+    grids = dict(GRIDS)
+    # the benchmarked model AT the benchmarked grid (~40 s of reference time per flavour on the box)
+    if os.environ.get("FW_FULL_DEPTH_HEADLINE", "1") == "1":
+        grids["headline_f21_60x104"] = (21, 60, 104)
+    if flavour == "wan22" and os.environ.get("FW_FULL_DEPTH_CONFIG4", "0") == "1":
+        grids["config4_f21_90x160"] = (21, 90, 160)
+    return grids
+
+
+def _reference_or_fail(model, cfg, ins, with_pred, parity, tag):
+    """The checker at a big grid must not vanish from a green run: out of memory fails the test unless the
+    leg was declared optional."""
+    try:
+        return _reference_forward(model, cfg, ins, with_pred)                  # the reference, fp32, PyTorch-ROCm
+    except torch.OutOfMemoryError as e:
+        torch.cuda.empty_cache()
+        if os.environ.get("FW_FULL_DEPTH_HEADLINE_OPTIONAL", "0") == "1" and not tag.split("/")[-1].startswith(("small", "production")):
+            parity.note(f"{tag}/checker_did_not_fit", str(e)[:160])
+            return None
+        pytest.fail(f"{tag}: the fp32 reference did not fit on the device ({str(e)[:200]}); "
+                    "FW_FULL_DEPTH_HEADLINE_OPTIONAL=1 records this as a note instead")
 
 
 @pytest.mark.parametrize("flavour", ["wan21", "wan22"])
@@ -141,35 +177,123 @@ def test_full_depth_model_matches_reference(flavour, parity):
     from fantasy_world_amd import install, uninstall, synth
     from fantasy_world_amd.hip_ops import HipOps
     cfg, model = _build(flavour)
-    grids = dict(GRIDS)
-    # the benchmarked model AT the benchmarked grid (Wan2.1: ~40 s of reference time on the box; FW_FULL_DEPTH_HEADLINE=0 skips it,
-    # =1 adds it for the Wan2.2 flavour too)
-    if os.environ.get("FW_FULL_DEPTH_HEADLINE", "1" if flavour == "wan21" else "0") == "1":
-        grids["headline_f21_60x104"] = (21, 60, 104)
     inputs, want = {}, {}
-    for name, (f, h2, w2) in grids.items():
+    for name, (f, h2, w2) in _grids(flavour).items():
         ins = synth.make_inputs(cfg, f, h2, w2, seed=11, device=DEV, dtype=torch.float32)
-        with_pred = name.startswith("small")
-        try:
-            want[name] = _reference_forward(model, cfg, ins, with_pred)                  # the reference, fp32, PyTorch-ROCm
-        except torch.OutOfMemoryError as e:                                                # headline grid: the checker's fp32 attention
-            if not name.startswith("headline"):
-                raise
-            parity.note(f"full_depth/{flavour}/{name}/checker_did_not_fit", str(e)[:160])
-            torch.cuda.empty_cache()
-            continue
-        inputs[name] = ins
+        w = _reference_or_fail(model, cfg, ins, name.startswith("small"), parity, f"full_depth/{flavour}/{name}")
+        if w is not None:
+            inputs[name], want[name] = ins, w
     eng = install(model, ops=HipOps(DEV), merge_cfg=False)
     assert eng.heads_cfg is not None and list(eng.heads_cfg.layer_idx) == [23, 17, 11, 7]
     assert [eng.cfg.has_adapter(b) for b in range(40)] == [flavour == "wan21" and b <= 24 for b in range(40)]
+    hip_rows = {}
     try:
         for name, ins in inputs.items():
             with_pred = name.startswith("small")
             got = _hip_forward(model, eng, cfg, ins, with_pred)
-            _compare(f"full_depth/{flavour}/{name}", parity, want.pop(name), got, cfg, with_pred)
+            keep = want[name] if (flavour == "wan21" and name == YARDSTICK_GRID) else want.pop(name)
+            hip_rows[name] = _compare(f"full_depth/{flavour}/{name}", parity, keep, got, cfg, with_pred)
             # and through the rebound method itself (B1), the call the reference's loop makes
             out, pred = model.joint_forward(ins["x"], **_kwargs(cfg, ins, False))
             torch.cuda.synchronize()
             assert pred is None and torch.equal(out, got[0])
     finally:
         uninstall(model)
+    del eng
+    torch.cuda.empty_cache()
+    if flavour == "wan21" and os.environ.get("FW_FULL_DEPTH_YARDSTICK", "1") == "1":
+        _yardstick(model, cfg, inputs[YARDSTICK_GRID], want.pop(YARDSTICK_GRID), hip_rows[YARDSTICK_GRID], parity)
+
+
+def _yardstick(model, cfg, ins, want, hip, parity):
+    """What bf16 storage of the activations costs at THIS depth, independent of any HIP kernel: the engine's host code (same op order,
+    same fusion of gates / residuals, same fp32 residual streams) on plain torch ops in fp32 with a bf16 rounding wherever the HIP path
+    stores bf16, against the same fp32 reference.  The HIP path is then read against that floor (VERDICT r04 "weak 1", "next" 6)."""
+    from fantasy_world_amd.engine import FusionEngine
+    from oracle.ref_ops import TorchRefOps
+    params = dict(model.named_parameters())
+    eng = FusionEngine(cfg, params.__getitem__, TorchRefOps(emulate_bf16=True, device=DEV))
+    got = _hip_forward(model, eng, cfg, ins, False)
+    wout, _, wcap = want
+    floor = {"noise_pred": rel_l2(got[0].float(), wout.float())}
+    for b in WATCH:
+        floor[f"x@{b}"] = rel_l2(got[2]["x"][b], wcap["x"][b])
+        if b >= cfg.start_index:
+            w = wcap["tok"][b]
+            floor[f"tok@{b}"] = rel_l2(got[2]["tok"][b].reshape(w.shape), w)
+    tag = f"full_depth/wan21/{YARDSTICK_GRID}/yardstick_bf16_rounding_on_torch_ops"
+    for k, v in floor.items():
+        parity.note(f"{tag}/{k}", {"floor": v, "hip": hip[k], "hip_over_floor": hip[k] / v})
+    print(tag, {k: f"{v:.2e} (hip {hip[k]:.2e})" for k, v in floor.items()})
+    # the HIP path may not sit far above the rounding floor of its own storage format (10 % is the review's figure for "find the kernel";
+    # the assert leaves room for the floor's own run-to-run spread of the torch kernels)
+    assert hip["noise_pred"] < 1.25 * floor["noise_pred"] + 2e-4, (hip["noise_pred"], floor["noise_pred"])
+
+
+# ---- BASELINE configs[4] ("Wan2.2 A14B fp8 MFMA path ... fp8 attention + FFN") at the benchmarked depth -------------------------
+# physical bounds (e4m3 carries 3 mantissa bits: one rounding is ~3e-2 of an element; the reference's own fp8 linears put it 2e-2 from its
+# fp32 run after TWO blocks, tests/test_config5_gpu.py); the tight bounds come from tests/golden/parity_bounds_gpu.json
+FP8_OUT_TOL, FP8_STREAM_TOL = 6e-2, 6e-2
+# fp8 attention has NO reference semantics (the reference defines fp8 for linears only, vram_management/layers.py:115-151): its pin is the
+# distance from the SAME engine with bf16 attention, fp8 linears in both -- STATED and enforced here (VERDICT r04 next 1b):
+FP8_ATTENTION_VS_BF16_ATTENTION_TOL = 2e-2
+
+
+def test_full_depth_fp8_linears_and_fp8_attention(parity):
+    """Wan2.2 flavour, 40 / 24 / 24 blocks.  (a) engine with precision="fp8" against the reference whose DiT-block nn.Linears are computed
+    by the reference's own fp8 linear (the modules enable_vram_management would wrap, oracle/ref_harness.py:swap_fp8_linears), streams
+    after blocks 15 / 24 / 25 / 39 so that e4m3's behaviour over depth is a curve; (b) fp8 attention on top against the fp8-linear
+    engine with bf16 attention, under FP8_ATTENTION_VS_BF16_ATTENTION_TOL."""
+    from fantasy_world_amd import install, uninstall, synth
+    from fantasy_world_amd.engine import FusionEngine
+    from fantasy_world_amd.hip_ops import HipOps
+    from oracle import ref_harness
+    cfg, model = _build("wan22")
+    ops = HipOps(DEV)
+    inputs, want32 = {}, {}
+    for name, (f, h2, w2) in GRIDS.items():
+        inputs[name] = synth.make_inputs(cfg, f, h2, w2, seed=11, device=DEV, dtype=torch.float32)
+        want32[name] = _reference_forward(model, cfg, inputs[name], False)
+
+    eng = install(model, ops=ops, merge_cfg=False, precision="fp8")
+    try:
+        got8 = {name: _hip_forward(model, eng, cfg, ins, False) for name, ins in inputs.items()}
+    finally:
+        uninstall(model)
+    del eng
+    # fp8 attention is an engine option the install() boundary does not expose (parity unpinned): built directly
+    params = dict(model.named_parameters())
+    eng = FusionEngine(cfg, params.__getitem__, ops, precision="fp8", fp8_attention=True)
+    got8a = {name: _hip_forward(model, eng, cfg, ins, False) for name, ins in inputs.items()}
+    del eng, params
+    torch.cuda.empty_cache()
+
+    assert ref_harness.swap_fp8_linears(model, cfg.start_index) == 40 * len(ref_harness.FP8_SITES)
+    for name, ins in inputs.items():
+        tag = f"full_depth_fp8/wan22/{name}"
+        w8 = _reference_forward(model, cfg, ins, False)             # the reference with ITS fp8 linear in those modules
+        (wout, _, wcap), (w32out, _, w32cap) = w8, want32[name]
+        (gout, _, gcap), (aout, _, acap) = got8[name], got8a[name]
+        assert torch.isfinite(gout.float()).all() and torch.isfinite(aout.float()).all()
+        rows = {"noise_pred": parity.check(f"{tag}/fp8_linear_engine_vs_reference_with_fp8_linears/noise_pred",
+                                           rel_l2(gout.float(), wout.float()), FP8_OUT_TOL)}
+        parity.note(f"{tag}/reference_with_fp8_linears_vs_reference_fp32/noise_pred", rel_l2(wout.float(), w32out.float()))
+        parity.note(f"{tag}/fp8_linear_engine_vs_reference_fp32/noise_pred", rel_l2(gout.float(), w32out.float()))
+        att = {"noise_pred": parity.check(f"{tag}/fp8_attention_vs_bf16_attention_engine/noise_pred",
+                                          rel_l2(aout.float(), gout.float()), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)}
+        parity.note(f"{tag}/fp8_attention_engine_vs_reference_with_fp8_linears__unpinned/noise_pred", rel_l2(aout.float(), wout.float()))
+        for b, what in WATCH.items():
+            rows[f"x@{b}"] = parity.check(f"{tag}/fp8_linear_engine_vs_reference_with_fp8_linears/x_stream_after_block_{b}_{what}",
+                                          rel_l2(gcap["x"][b], wcap["x"][b]), FP8_STREAM_TOL)
+            parity.note(f"{tag}/reference_with_fp8_linears_vs_reference_fp32/x_stream_after_block_{b}_{what}",
+                        rel_l2(wcap["x"][b], w32cap["x"][b]))
+            att[f"x@{b}"] = parity.check(f"{tag}/fp8_attention_vs_bf16_attention_engine/x_stream_after_block_{b}_{what}",
+                                         rel_l2(acap["x"][b], gcap["x"][b]), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
+            if b >= cfg.start_index:
+                w = wcap["tok"][b]
+                rows[f"tok@{b}"] = parity.check(f"{tag}/fp8_linear_engine_vs_reference_with_fp8_linears/vggt_stream_after_block_{b}_{what}",
+                                                rel_l2(gcap["tok"][b].reshape(w.shape), w), FP8_STREAM_TOL)
+                att[f"tok@{b}"] = parity.check(f"{tag}/fp8_attention_vs_bf16_attention_engine/vggt_stream_after_block_{b}_{what}",
+                                               rel_l2(acap["tok"][b], gcap["tok"][b]), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
+        print(tag, "fp8 linears vs reference-with-fp8-linears", {k: f"{v:.2e}" for k, v in rows.items()})
+        print(tag, "fp8 attention vs bf16 attention (fp8 linears in both)", {k: f"{v:.2e}" for k, v in att.items()})

@@ -48,5 +48,20 @@ for rep in range(3):
         for _ in range(4): ops.linear(x, lin, out=out)
     for _ in range(4): torch.matmul(x, w.t(), out=out)
     for _ in range(4): ops.attention(qs.repeat(1, 4)[:, :1024].contiguous(), k.repeat(1, 4)[:, :1024].contiguous(), v.repeat(1, 4)[:, :1024].contiguous(), 8, 128, q_prescaled=True)
+# round 5: the other attention kernels (hd 96 / hd 64 were never probed after the descriptor change) and fp8
+L2 = 32865
+q96 = mk(L, 12 * 96); k96 = mk(L2, 12 * 96); v96 = mk(L2, 12 * 96)
+q96 = (q96.float() * ops.q_scale(96)).to(torch.bfloat16)
+q64 = mk(L2, 16 * 64); k64 = mk(L2, 16 * 64); v64 = mk(L2, 16 * 64)
+q64 = (q64.float() * ops.q_scale(64)).to(torch.bfloat16)
+q8s = (q.float() * ops.q_scale_fp8(128)).to(torch.bfloat16).repeat(1, 4)[:, :1024].contiguous()
+k8 = ops.cast_fp8(k.repeat(1, 4)[:, :1024].contiguous()); q8 = ops.cast_fp8(q8s)
+vt8, lk8 = ops.prepare_v_fp8(v.repeat(1, 4)[:, :1024].contiguous(), 8, 128)
+k96s = (k96.float() * ops.q_scale(96)).to(torch.bfloat16); q96r = mk(L, 12 * 96)
+for rep in range(3):
+    for _ in range(4): ops.attention(q96, k96, v96, 12, 96, q_prescaled=True)
+    for _ in range(4): ops.attention(k96s, q96r, q96r, 12, 96, q_prescaled=True)
+    for _ in range(4): ops.attention(q64, k64, v64, 16, 64, q_prescaled=True)
+    for _ in range(4): ops.attention_fp8(q8, k8, vt8, 8, 128, lk8)
 torch.cuda.synchronize()
 ops.set_option("gemm_kernel", 9)
