@@ -108,15 +108,46 @@ def forward_flops(cfg, L, L2, S, P, Lc, Li):
     return 2.0 * macs
 
 
-def attention_cap(hd):
-    """What bounds an attention launch of head size hd on this SIMD (docs/kernels.md, "attention: the cap"): per 64-key tile of 32 query
-    rows a wave spends 8 hd cycles in MFMAs and ~533 cycles in the softmax's VALU work (32 v_exp_f32 + 32 adds + 16 packs), and the two
-    do NOT overlap between the two waves of a SIMD -- the sum fits the measured per-tile times of hd 128 / 96 / 64 to 1 %
-    (profiles/r03/microbench_attention_variants.txt).  The matrix-pipe fraction is therefore capped at hd / (hd + 66.6) of the peak at
-    the clock the chip sustains (~1.9-2.0 of 2.4 GHz on random data), whatever the schedule."""
-    cap = hd / (hd + 66.6)
-    return {"mfma_frac_at_sustained_clock": round(cap, 3), "frac_of_2p5_pf_at_1p95_ghz": round(cap * 1.95 / 2.4, 3),
-            "model": "8*hd MFMA cycles + 533 VALU cycles per 64-key tile and wave, not overlapping"}
+def attention_measured(hd):
+    """What the matrix pipe does under the attention launch of head size hd: STORED measurements (a PMC pass cannot run inside the
+    timed process), one rocprofv3 --pmc pass of tools/clock_probe.sh on the launch shapes of the headline workload with random data --
+    `mfma_busy` = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, `sustained_ghz` = GRBM_GUI_ACTIVE / duration (the chip is power-limited
+    under these kernels: 1.5-1.7 of 2.4 GHz).  busy x ghz / 2.4 is the fraction of the 2.5 PF peak those two numbers predict; the
+    remaining (1 - busy) of the cycles have no MFMA in flight (docs/kernels.md, "where the other cycles go").  Replaces the round-3/4
+    `roofline_cap` model (8 hd MFMA + 533 VALU cycles per tile, "0.658 at 1.95 GHz"), which the round-4 counters contradicted."""
+    for rnd in ("r05", "r04"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "attn_counters.json")) as f:
+                rec = json.load(f)["hd%d" % hd]
+            busy, ghz = float(rec["mfma_busy"]), float(rec["sustained_ghz"])
+            return {"mfma_busy": busy, "sustained_ghz": ghz, "predicted_frac_of_2p5_pf": round(busy * ghz / 2.4, 3),
+                    "source": "stored PMC pass (not measured in this process): profiles/%s/%s" % (rnd, rec.get("file", "attn_counters.json"))}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+class _AltGuard:
+    """The `alt` loop of an N > 1 run must never cost the headline line: if it has not finished `budget_s` seconds after it started
+    (a collective one rank never issues, an engine build that crawls), rank 0 prints the line it already has -- `alt` = the error --
+    and every rank leaves with exit code 0.  A timer thread: the main thread may be blocked inside a collective (GIL released)."""
+
+    def __init__(self, line, rank, budget_s):
+        import threading
+        self.line, self.rank, self.budget_s = line, rank, budget_s
+        self._t = threading.Timer(budget_s, self._fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def _fire(self):
+        if self.rank == 0:
+            self.line["alt"] = {"error": f"the second partition did not finish within {self.budget_s:.0f} s; headline line printed without it"}
+            print(json.dumps(self.line), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+
+    def cancel(self):
+        self._t.cancel()
 
 
 def dry_run(args):
@@ -156,12 +187,39 @@ def dry_run(args):
     tt = torch.tensor([time.time() - t0], dtype=torch.float64)
     if topo.world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    line = {"metric": "denoise-steps/sec (DRY RUN: launcher / topology / collectives only, no engine)",
+            "value": None, "unit": "denoise-steps/s", "n_gpus": topo.world, "steps": args.steps,
+            "warmup": args.warmup, "dry_run": True, "wall_s": float(tt.item()),
+            "config": {"workload": "dry run", "parallelism": topo.describe()},
+            "comm": stats.summary(args.warmup + args.steps)}
+    # the `alt` block of a real N > 1 run: the OTHER partition's groups over the same ranks, its collectives, under the same guard
+    if os.environ.get("FW_BENCH_ALT", "1") != "0":
+        topo2 = parallel.alt_topology(topo)
+        if topo2 is not None:
+            guard = _AltGuard(line, topo.rank, float(os.environ.get("FW_BENCH_ALT_BUDGET_S", "120")))
+            stats.records.clear()
+            n_alt = max(1, min(args.steps, int(os.environ.get("FW_BENCH_ALT_STEPS", "5"))))
+            t1 = time.time()
+            if os.environ.get("FW_BENCH_ALT_FORCE_HANG") == "1":       # test hook: the alt loop never finishes
+                time.sleep(3600)
+            for _ in range(n_alt):
+                if topo2.tp is not None:
+                    tot = topo2.tp.all_reduce_async(torch.ones(8)).wait()
+                    assert float(tot[0]) == topo2.tp.world
+                if topo2.shard is not None:
+                    sh2 = topo2.shard
+                    sh2.localize_tables(dict(dit=torch.zeros(F * hw, 2), bi_dit=torch.zeros(F * hw, 2), bi_agg=torch.zeros(F * (5 + hw), 2)),
+                                        F, hw, 5)
+                    full = sh2.all_gather_rows(torch.randn(sh2.dit_counts[sh2.rank], 4), sh2.dit_counts)
+                    assert full.shape[0] == F * hw
+                if topo2.cfg_groups == 2:
+                    topo2.gather_cfg(torch.full((4,), float(topo2.cfg_rank)))
+            dist.barrier()
+            guard.cancel()
+            line["alt"] = {"parallelism": topo2.describe(), "value": None, "steps": n_alt, "wall_s": time.time() - t1,
+                           "comm": stats.summary(n_alt)}
     if topo.rank == 0:
-        print(json.dumps({"metric": "denoise-steps/sec (DRY RUN: launcher / topology / collectives only, no engine)",
-                          "value": None, "unit": "denoise-steps/s", "n_gpus": topo.world, "steps": args.steps,
-                          "warmup": args.warmup, "dry_run": True, "wall_s": float(tt.item()),
-                          "config": {"workload": "dry run", "parallelism": topo.describe()},
-                          "comm": stats.summary(args.warmup + args.steps)}), flush=True)
+        print(json.dumps(line), flush=True)
     if topo.world > 1:
         dist.destroy_process_group()
 
@@ -255,12 +313,17 @@ def main():
     # Wan2.2: high-noise expert above the boundary (inference_wan22.py:229-240; 0.9 * 1000 for the A14B pair)
     boundary = 900.0
 
-    def one_step(step_id, latents):
+    n_sched = len(sched.timesteps)
+
+    def one_step(step_id, latents, merge=None, engines_=None, topo_=None):
+        step_id %= n_sched                      # a long run walks the 50-step schedule again (throughput does not depend on the timestep)
+        merge = args.merge_cfg if merge is None else merge
+        es, tp_ = engines_ or engines, topo_ or topo
         if n_experts == 2:
-            return denoise_step_dual(engines[0], engines[1], boundary, sched, step_id, latents, ins["context"],
-                                     ins["context_neg"], cond, topo=topo, merge_cfg=args.merge_cfg)[0]
-        return denoise_step(eng, sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=topo,
-                            merge_cfg=args.merge_cfg)[0]
+            return denoise_step_dual(es[0], es[1], boundary, sched, step_id, latents, ins["context"],
+                                     ins["context_neg"], cond, topo=tp_, merge_cfg=merge)[0]
+        return denoise_step(es[0], sched, step_id, latents, ins["context"], ins["context_neg"], cond, topo=tp_,
+                            merge_cfg=merge)[0]
 
     def barrier():
         if world > 1:
@@ -302,6 +365,35 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(latents.float()).all(), "non-finite latents"
 
+    # N = 1: the configuration install() gives a user of the reference by default -- step-invariant cache ON, the two CFG forwards of a step
+    # merged into one pass (bit-identical outputs) -- timed after the headline region on the same engines, so a driver
+    # record carries it.  Reported as `value_dropin`, never as `value`.  FW_BENCH_DROPIN=0 skips it.
+    dropin = None
+    if world == 1 and os.environ.get("FW_BENCH_DROPIN", "1") != "0" and not (args.merge_cfg and args.cache_invariants):
+        n_d = max(1, min(args.steps, int(os.environ.get("FW_BENCH_DROPIN_STEPS", "5"))))
+        for e in engines:
+            e.invariants.enabled = True
+        lat_d, sid = latents, step_id
+        for _ in range(n_experts):                                   # fills the caches (per expert): untimed
+            lat_d = one_step(sid, lat_d, merge=True)
+            sid += 1
+        barrier()
+        t0d = time.time()
+        for _ in range(n_d):
+            lat_d = one_step(sid, lat_d, merge=True)
+            sid += 1
+        barrier()
+        dtd = time.time() - t0d
+        assert torch.isfinite(lat_d.float()).all(), "non-finite latents (drop-in configuration)"
+        for e in engines:
+            e.invariants.enabled = bool(args.cache_invariants)
+            e.invariants.clear()
+        dropin = {"value": n_d / dtd, "ms_per_step": 1e3 * dtd / n_d, "steps": n_d, "step_invariant_cache": True,
+                  "cfg_merged_in_one_pass": True,
+                  "note": "install()'s defaults (INTEGRATION.md): bit-identical outputs to the headline configuration; `value` stays the "
+                          "reference's per-step work (cache off, two forwards)"}
+        del lat_d
+
     fp8_attn = bool(getattr(eng, "fp8_attention", False))        # what the engine that was BUILT runs, not what was asked for
     Li = cfg.clip_tokens if cfg.has_image_input else 0
     f_fwd = forward_flops(cfg, L, L2, F, P, 512, Li)
@@ -335,18 +427,19 @@ def main():
                          "tflops": None if fl is None else fl / (ms * 1e-3) / 1e12,
                          "frac_of_bf16_peak": None if fl is None else fl / (ms * 1e-3) / MFMA_BF16_PEAK}
         if name.startswith("attn_hd") and fl is not None:
-            kernels[name]["roofline_cap"] = attention_cap(int(name[7:].split("_")[0]))
+            kernels[name]["matrix_pipe"] = attention_measured(int(name[7:].split("_")[0]))
     # HBM-side traffic of the dominant kernel: measured with rocprofv3 PMC counters in separate passes (FETCH_SIZE, WRITE_SIZE)
     # as MI355X_MICROARCH.md prescribes, recorded under profiles/ with provenance; bench.py only reports the stored measurement
     # (a PMC pass cannot run inside the timed process).  Valid for the headline launch shape only.
-    traffic = None
+    traffic, traffic_source = None, None
     headline = (not wan22 and args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
                 and args.precision == "bf16")
     if headline and sp == 1:
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                     traffic = nb * float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])    # merged CFG: batch 2 per launch
+                traffic_source = f"stored PMC pass (not measured in this process): profiles/{rnd}/pmc_traffic.json, headline launch shape only"
                 break
             except (OSError, KeyError, ValueError):
                 continue
@@ -378,12 +471,15 @@ def main():
                                + ("" if topo.tp is None else f", {cfg.num_heads // sp} of {cfg.num_heads} heads per tensor-parallel rank") + ")",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
-                     "flops_per_launch": attn_flops, "traffic": traffic,
+                     "flops_per_launch": attn_flops, "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*/pmc_traffic.json)",
                      "algorithmic_bytes_per_launch": nb * 4.0 * L * cfg.dim * 2 / sp / n_groups,
-                     "roofline_cap": attention_cap(cfg.head_dim)},
+                     "matrix_pipe": None if fp8_attn else attention_measured(cfg.head_dim)},
         "kernels": kernels,
     }
+    if dropin is not None:
+        out["value_dropin"] = dropin["value"]
+        out["dropin"] = dropin
     if args.precision == "fp8":
         out["mfma_frac_whole_step_vs_fp8_peak"] = step_flops * value / (world * peak)
     if args.hip_graph and world == 1 and n_experts == 1:
@@ -440,6 +536,60 @@ def main():
         comm["note"] = ("per GPU (this is rank 0); exposed = time the compute stream was blocked inside Pending.wait(); "
                         "issue_to_done = issue -> completion windows summed (upper bound on the exchanges' own duration)")
         out["comm"] = comm
+    # N > 1: the OTHER partition (FW_PARALLEL's alternative: tensor-parallel heads / FFN columns + all-reduce -- north_star's -- when the
+    # headline ran the CFG x sequence-shard default, and vice versa) in the same process group, a shorter loop, printed as `alt` beside
+    # the headline `value`: the first hardware run then answers both partition questions.  Guarded: if it does not
+    # finish inside FW_BENCH_ALT_BUDGET_S the headline line is printed without it.  FW_BENCH_ALT=0 skips it.
+    if world > 1 and os.environ.get("FW_BENCH_ALT", "1") != "0" and not fp8_attn:
+        topo2 = parallel.alt_topology(topo)
+        if topo2 is not None:
+            out["watchdog_s"] = wd
+            if golden is not None:
+                out["golden_check"] = golden
+            if wd > 0:
+                faulthandler.cancel_dump_traceback_later()             # the guard below owns the clock from here
+            guard = _AltGuard(out, rank, float(os.environ.get("FW_BENCH_ALT_BUDGET_S", "420")))
+            alt = {"parallelism": topo2.describe()}
+            try:
+                if os.environ.get("FW_BENCH_GOLDEN_CHECK", "1") != "0":
+                    alt["golden_check"] = parallel.golden_self_check(topo2, ops)
+                if alt.get("golden_check", {"ok": True})["ok"]:
+                    t0 = time.time()
+                    engines2 = [parallel.make_engine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s),
+                                                     ops, topo2, cache_step_invariants=args.cache_invariants, precision=args.precision)
+                                for s in range(n_experts)]
+                    torch.cuda.synchronize()
+                    alt["engine_build_s"] = round(time.time() - t0, 1)
+                    n_alt = max(1, min(args.steps, int(os.environ.get("FW_BENCH_ALT_STEPS", "5"))))
+                    lat2, sid = ins["x"], 0
+                    for _ in range(n_experts):
+                        lat2 = one_step(sid, lat2, engines_=engines2, topo_=topo2)
+                        sid += 1
+                    stats.records.clear()
+                    barrier()
+                    t0 = time.time()
+                    for _ in range(n_alt):
+                        lat2 = one_step(sid, lat2, engines_=engines2, topo_=topo2)
+                        sid += 1
+                    barrier()
+                    dt2 = torch.tensor([time.time() - t0], device=dev, dtype=torch.float64)
+                    torch.distributed.all_reduce(dt2, op=torch.distributed.ReduceOp.MAX)
+                    dt2 = float(dt2.item())
+                    finite = bool(torch.isfinite(lat2.float()).all())
+                    alt.update(value=(n_alt / dt2) if finite else None, ms_per_step=1e3 * dt2 / n_alt, steps=n_alt, warmup=n_experts,
+                               finite=finite, mfma_frac_whole_step=step_flops * (n_alt / dt2) / (world * MFMA_BF16_PEAK),
+                               comm=stats.summary(n_alt))
+                    if topo2.tp is not None:
+                        alt["comm"]["tp_reduce_dtype"] = str(topo2.tp.reduce_dtype).replace("torch.", "")
+                    if topo2.shard is not None:
+                        alt["comm"]["exchange_groups"] = topo2.shard.exchange_probe
+                    del engines2
+                else:
+                    alt["value"], alt["error"] = None, "the second partition is off the reference golden: no throughput reported for it"
+            except Exception as e:            # NOTE: a per-rank exception here can leave other ranks in a collective: the guard ends that
+                alt["value"], alt["error"] = None, repr(e)[:300]
+            guard.cancel()
+            out["alt"] = alt
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del engines, eng
         torch.cuda.empty_cache()

@@ -493,6 +493,357 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_pp_kernel(Attn8Args p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: single-stream kernel (default).  Counters of the ping-pong kernel above (profiles/r05/clock_probe_call1.txt): matrix pipe
+// 35 % busy at 2.19 GHz -- ~1550 cycles per wave and 64-key tile for 512 cycles of MFMA: two barriers per tile and a vector segment
+// nobody's MFMAs cover.  This kernel is attention_sp_kernel's structure (attention.hip) on the fp8 MFMA:
+//   * ONE instruction stream per wave: stage A(t) = the 4 QK^T MFMAs of tile t+1 with the 32 exponentials / 16 e4m3 packs of tile t and
+//     the reads of the Vt(t) fragments between them; stage B(t) = the PV MFMAs of tile t with the reads of the K(t+2) fragments and the
+//     row maximum of tile t+1 between them.  One barrier per tile, 4-slot K / Vt rings, the tile loop unrolled by the ring depth (ring
+//     slots are immediates of the ds_reads), tile requests by SGPR descriptor + scalar tile offset (rows past the last key: zeros).
+//   * ROW SUMS ON THE MATRIX PIPE: a fifth PV MFMA whose A operand is the constant 1.0 (e4m3 0x38; no LDS read) leaves, in every
+//     register of its accumulator, the sum over the tile's keys of the e4m3-ROUNDED probabilities of the lane's query -- the 32 fp32
+//     adds per tile, the cross-half exchange at the end, and the mismatch between a normaliser summed before rounding and a numerator
+//     summed after it all go away.  One MFMA in nine is then not algorithmic work; at half the matrix cycles of the bf16 kernel for the
+//     same softmax this kernel is bound by vector issue, and that is the trade that pays (the bf16 kernels, matrix-bound, measured
+//     the same idea as a loss).  VAR bit 0 keeps the fp32 adds instead (A/B arm).
+// Same shift rule as the kernels above: M is set from the first tile (largest P = 2^7), moves only when a later score would push P
+// past 2^8; the rescale is a rarely taken branch at the top of a tile.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int RING_SP = 8;
+
+// max of the 16 values of an accumulator: 7 v_max3 + 1 v_max in ONE asm statement (no per-op canonicalisation).  Callers keep well over
+// the 18 wait states of a 16-pass MFMA between the MFMA that writes `v` and this read (a block's exponentials sit in between).
+__device__ __forceinline__ float fw8_max16(const f32x16_t& v) {
+    float r, t;
+    asm("v_max3_f32 %0, %2, %3, %4\n\t"
+        "v_max3_f32 %1, %5, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %1, %1, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %1, %1, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17\n\t"
+        "v_max_f32 %0, %0, %1"
+        : "=&v"(r), "=&v"(t)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    return r;
+}
+
+// Register budget (two waves per SIMD: 256): a 64-key tile of scores is never held whole.  The score pipeline runs on 32-key BLOCKS:
+//   A0(t): S1(t) = K1(t) Q^T - M (2 MFMAs)      ||  P of block 0 of tile t from S0 (16 exp, 8 packs), Vt(t) d-blocks 0, 1 -> fr[0..1]
+//   A1(t): S0(t+1) = K0(t+1) Q^T - M (2 MFMAs)  ||  P of block 1 of tile t from S1,                    Vt(t) d-blocks 2, 3 -> fr[2..3]
+//   B(t):  O^T += Vt(t) P(t)^T (4 MFMAs) + row sums (1 MFMA)  ||  K1(t+1) -> fr[0..1], K0(t+2) -> fr[2..3], row maximum of S0(t+1)
+// so two 16-register score blocks are live instead of four.  The two blocks of a tile share ONE shift (the PV MFMA contracts over both):
+// block 0's overflow test runs at the top of the tile, block 1's between A0 and A1, where S0 is still intact and the (rare) repair
+// re-exponentiates block 0 under the new shift.
+// THE TWO WAVES OF A SIMD RUN HALF A TILE APART (VAR bit 1 = 0; bit 1 set = all eight waves in phase, the A/B arm).  In phase, both
+// waves of a SIMD are in the vector-bound stages A together and in the matrix-only stage B together: the stage times ADD (measured:
+// ~2490 cycles per tile and SIMD for 1152 matrix cycles).  Every wave executes ONE s_barrier per tile; waves 0-3 at the END of the
+// tile, waves 4-7 BETWEEN stages A1 and B -- so after the first barrier waves 4-7 run stage B(t) beside stage A(t+1) of waves 0-3, and
+// a SIMD always has one wave on the vector side and one on the matrix side.  8-slot rings (128 KiB) keep the tile requests clear of
+// both groups' reads: K(t+5) / Vt(t+3) are requested at the top of tile t into the slots of K(t-3) / Vt(t-5), and the wait before a
+// barrier leaves the four newest requests in flight.
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
+    constexpr bool VALU_SUM = (VAR & 1) != 0;
+    constexpr bool SKEW = (VAR & 2) == 0;
+    __shared__ __attribute__((aligned(16))) char smem[RING_SP * (K8_TILE + V8_TILE)];      // 128 KiB
+    constexpr int V_BASE = RING_SP * K8_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = SKEW && wave >= 4;          // the half of the work-group whose barrier sits in the middle of its tile
+    const int fi = lane & 31, hi = lane >> 5;
+
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint8_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD;
+    const uint8_t* Kp = p.K + (int64_t)b * p.bsk + (int64_t)h * HD;
+    const uint8_t* Vp = p.Vt + ((int64_t)b * p.heads + h) * HD * p.lkp;
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD;
+
+    const int q_row = qb * QB + wave * 32 + fi;
+    i32x8_t qf[2];
+    {
+        const uint8_t* src = Qp + (int64_t)min(q_row, p.Lq - 1) * p.ldq + hi * 32;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) qf[c] = frag32((const char*)src + c * 64, (const char*)src + c * 64 + 16);
+    }
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+    const int qs = p.q_scale_e8m0;
+
+    // ---- tile requests: one 1 KiB K piece (8 key rows) and one 1 KiB Vt piece (16 d rows) per wave and tile, through descriptors over
+    // this (batch, head)'s K rows / Vt rows: lane offset in a VGPR, the tile's byte offset is the scalar offset; rows past the last key
+    // are outside the K descriptor (zeros; their scores are masked)
+    const int krow = wave * 8 + (lane >> 3);
+    const int koff = krow * (int)p.ldk + (((lane & 7) ^ ((krow >> 1) & 7)) << 4);
+    const int vrow = wave * 16 + (lane >> 2);
+    const int voff = vrow * (int)p.lkp + (((lane & 3) ^ ((vrow >> 2) & 3)) << 4);
+    const size_t kbytes = (size_t)p.Lk * (size_t)p.ldk, vbytes = (size_t)HD * (size_t)p.lkp;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(unsigned)kbytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)vbytes, 0x00020000);
+    const int k_tile_stride = KVB * (int)p.ldk;
+    auto issue_k = [&](int t, int slot) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, FW_LDS_PTR(smem + (slot & (RING_SP - 1)) * K8_TILE + wave * 1024), 16, koff,
+                                                 t * k_tile_stride, 0, 0);
+    };
+    auto issue_v = [&](int t, int slot) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, FW_LDS_PTR(smem + V_BASE + (slot & (RING_SP - 1)) * V8_TILE + wave * 1024), 16, voff,
+                                                 t * KVB, 0, 0);
+    };
+
+    // ---- fragment read offsets (the ring slot and the key / d block are immediates on top)
+    int kco[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) kco[c][e] = fi * 128 + (((4 * c + 2 * hi + e) ^ ((fi >> 1) & 7)) << 4);
+    int vco[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) vco[e] = V_BASE + fi * 64 + (((2 * hi + e) ^ ((fi >> 2) & 3)) << 4);
+
+    f32x16_t o[4], osum, negM;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { osum[r] = 0.f; negM[r] = 0.f; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float M = 0.f, l_run = 0.f, mx0 = 0.f;
+    i32x8_t fr[4];
+    f32x16_t S0, S1;                        // scores (minus M) of key block 0 / 1
+    int pw[8];                              // P(t) in e4m3: words 0..3 = block 0, 4..7 = block 1
+
+    // K fragment of tile-slot `slot`, key block blk, hd chunk c
+    auto k_frag = [&](int slot, int blk, int c) __attribute__((always_inline)) {
+        const char* base = smem + slot * K8_TILE + blk * 32 * 128;
+        return frag32(base + kco[c][0], base + kco[c][1]);
+    };
+    auto set_negM = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negM[r] = -M;
+    };
+    auto mask_block = [&](f32x16_t& s, int t, int blk) __attribute__((always_inline)) {
+        const int kbase = t * KVB + blk * 32 + 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kbase + (r & 3) + 8 * (r >> 2) >= p.Lk) s[r] = -1.0e30f;
+    };
+    auto row_max = [&](const f32x16_t& s) __attribute__((always_inline)) {
+        const float mx = fw8_max16(s);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(sw[0]), "v"(sw[1]));
+        return r;
+    };
+    // 8 scores s[8g .. 8g+7] -> two e4m3 words; returns their fp32 sum (used by the VALU_SUM arm only)
+    auto exp_pack8 = [&](const f32x16_t& s, int g, int& w0, int& w1) __attribute__((always_inline)) {
+        const float a0 = __builtin_amdgcn_exp2f(s[8 * g]), a1 = __builtin_amdgcn_exp2f(s[8 * g + 1]);
+        const float a2 = __builtin_amdgcn_exp2f(s[8 * g + 2]), a3 = __builtin_amdgcn_exp2f(s[8 * g + 3]);
+        const float a4 = __builtin_amdgcn_exp2f(s[8 * g + 4]), a5 = __builtin_amdgcn_exp2f(s[8 * g + 5]);
+        const float a6 = __builtin_amdgcn_exp2f(s[8 * g + 6]), a7 = __builtin_amdgcn_exp2f(s[8 * g + 7]);
+        // (the `old` operand of the first conversion is a dead value, not a zero: no v_mov to initialise the destination)
+        int x = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, __float_as_int(a0), false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, x, true);
+        int y = __builtin_amdgcn_cvt_pk_fp8_f32(a4, a5, __float_as_int(a4), false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(a6, a7, y, true);
+        return VALU_SUM ? ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) : 0.f;
+    };
+    // everything accumulated so far shrinks by 2^-delta
+    auto shrink = [&](float delta) __attribute__((always_inline)) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    };
+
+    // the shift moves up by delta (rare after the first tiles): everything accumulated so far shrinks by 2^-delta
+    auto rescale = [&](float delta) __attribute__((always_inline)) {
+        shrink(delta);
+        M += delta;
+        set_negM();
+    };
+
+    // own fragment reads done, own requests done except the four newest (K(t+4), K(t+5), Vt(t+2), Vt(t+3) at a barrier of tile t:
+    // K <= t+3 and Vt <= t+1 have landed), then the work-group barrier that publishes everybody's
+    auto sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fw8_wait_vm<4>();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // One tile.  On entry: S0 = block 0 of S(t) - M, mx0 = its row maximum, fr[0..1] = K1(t) fragments, fr[2..3] = K0(t+1) fragments.
+    // SLT: ring slot of tile t (compile time, or -1);  NEXT / NEXT2: tiles t+1 / t+2 exist;  MASK: tile t is a ragged last tile;
+    // MASKN: tile t+1 is.
+    auto tile = [&](int t, auto slot_tag, auto next_tag, auto next2_tag, auto mask_tag, auto maskn_tag) __attribute__((always_inline)) {
+        constexpr int SLT = decltype(slot_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value;
+        constexpr bool MASK = decltype(mask_tag)::value, MASKN = decltype(maskn_tag)::value;
+        const int sl = SLT >= 0 ? SLT : (t & (RING_SP - 1));
+        const int sl1 = SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : ((t + 1) & (RING_SP - 1));
+        const int sl2 = SLT >= 0 ? ((SLT + 2) & (RING_SP - 1)) : ((t + 2) & (RING_SP - 1));
+        if (__builtin_expect(__any(mx0 > 8.0f), 0)) {   // block 0 would overflow e4m3: move the shift so that the largest P is 2^7 again
+            const float delta = fmaxf(mx0 - 7.0f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S0[r] -= delta;
+            rescale(delta);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (NEXT) {                             // requests: K(t+5) into the slot of K(t-3), Vt(t+3) into the slot of Vt(t-5): dead for all
+            issue_k(min(t + 5, nt - 1), t + 5);
+            issue_v(min(t + 3, nt - 1), t + 3);
+        }
+        const char* vbase = smem + sl * V8_TILE;
+        float ls = 0.f;
+        // Every MFMA and the vector / LDS work that rides in its shadow form ONE scheduling region (sched_barrier fences): the
+        // interleave is the program order written here, not the scheduler's choice.
+#define FW8_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // ---- A0: S1(t) (2 MFMAs)  ||  P of block 0; Vt d-blocks 0, 1
+        FW8_FENCE();
+        S1 = FW8_MFMA(fr[0], qf[0], negM, qs);
+        FW8_FENCE();
+        ls += exp_pack8(S0, 0, pw[0], pw[1]);
+        fr[0] = frag32(vbase + vco[0], vbase + vco[1]);
+        FW8_FENCE();
+        S1 = FW8_MFMA(fr[1], qf[1], S1, qs);
+        FW8_FENCE();
+        ls += exp_pack8(S0, 1, pw[2], pw[3]);
+        fr[1] = frag32(vbase + 32 * 64 + vco[0], vbase + 32 * 64 + vco[1]);
+        // block 0's probabilities are FINAL here in the common case: keep them on this side of the branch below (the compiler
+        // otherwise sinks the exponentials behind it, and the row maximum then waits for the MFMAs with nothing to do)
+        asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]));
+        FW8_FENCE();
+        if (MASK) mask_block(S1, t, 1);
+        {
+            const float mx1 = row_max(S1);
+            if (__builtin_expect(__any(mx1 > 8.0f), 0)) {      // rare: block 1 would overflow e4m3 under the tile's shift -- redo block 0
+                const float delta = fmaxf(mx1 - 7.0f, 0.f);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
+                rescale(delta);
+                ls = exp_pack8(S0, 0, pw[0], pw[1]);
+                ls += exp_pack8(S0, 1, pw[2], pw[3]);
+            }
+        }
+        FW8_FENCE();
+        // ---- A1: block 0 of S(t+1) (2 MFMAs)  ||  P of block 1; Vt d-blocks 2, 3
+        if (NEXT) S0 = FW8_MFMA(fr[2], qf[0], negM, qs);
+        FW8_FENCE();
+        ls += exp_pack8(S1, 0, pw[4], pw[5]);
+        fr[2] = frag32(vbase + 2 * 32 * 64 + vco[0], vbase + 2 * 32 * 64 + vco[1]);
+        FW8_FENCE();
+        if (NEXT) S0 = FW8_MFMA(fr[3], qf[1], S0, qs);
+        FW8_FENCE();
+        ls += exp_pack8(S1, 1, pw[6], pw[7]);
+        fr[3] = frag32(vbase + 3 * 32 * 64 + vco[0], vbase + 3 * 32 * 64 + vco[1]);
+        if (VALU_SUM) l_run += ls;
+        FW8_FENCE();
+        if (NEXT && late) sync();               // waves 4-7: this tile's barrier (they run stage B beside the others' next stage A)
+        const i32x8_t pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+        // ---- B: O^T += Vt(t) P(t)^T (+ the row sums)  ||  K1(t+1), K0(t+2) fragments; ragged mask and row maximum of block 0 of S(t+1)
+        if (!VALU_SUM) {
+            // A operand = 1.0 in every e4m3 byte, written into registers the exponentials have just released (8 v_mov per tile
+            // against the 32 adds they replace): a resident block would not fit beside the accumulators
+            const i32x8_t ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
+            osum = FW8_MFMA(ones, pf, osum, 0x7f7f7f7f);
+            FW8_FENCE();
+        }
+        o[0] = FW8_MFMA(fr[0], pf, o[0], 0x7f7f7f7f);
+        if (NEXT) fr[0] = k_frag(sl1, 1, 0);
+        FW8_FENCE();
+        o[1] = FW8_MFMA(fr[1], pf, o[1], 0x7f7f7f7f);
+        if (NEXT) fr[1] = k_frag(sl1, 1, 1);
+        FW8_FENCE();
+        o[2] = FW8_MFMA(fr[2], pf, o[2], 0x7f7f7f7f);
+        if (NEXT2) fr[2] = k_frag(sl2, 0, 0);
+        FW8_FENCE();
+        o[3] = FW8_MFMA(fr[3], pf, o[3], 0x7f7f7f7f);
+        if (NEXT2) fr[3] = k_frag(sl2, 0, 1);
+#undef FW8_FENCE
+        if (NEXT) {
+            if (MASKN) mask_block(S0, t + 1, 0);
+            mx0 = row_max(S0);
+            if (!late) sync();                   // waves 0-3 (all eight when not skewed): this tile's barrier
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using SR = std::integral_constant<int, -1>;
+
+    // ---- prologue: K(0..4), Vt(0..2) requested; both blocks of S(0) for the shift; then the fragments tile 0 starts from
+    issue_k(0, 0);
+    issue_k(min(1, nt - 1), 1);
+    issue_k(min(2, nt - 1), 2);
+    issue_k(min(3, nt - 1), 3);
+    issue_k(min(4, nt - 1), 4);
+    issue_v(0, 0);
+    issue_v(min(1, nt - 1), 1);
+    issue_v(min(2, nt - 1), 2);
+    fw8_wait_vm<0>();
+    FW8_BARRIER();
+    S0 = FW8_MFMA(k_frag(0, 0, 0), qf[0], negM, qs);
+    S0 = FW8_MFMA(k_frag(0, 0, 1), qf[1], S0, qs);
+    fr[0] = k_frag(0, 1, 0);
+    fr[1] = k_frag(0, 1, 1);
+    S1 = FW8_MFMA(fr[0], qf[0], negM, qs);
+    S1 = FW8_MFMA(fr[1], qf[1], S1, qs);
+    if (ragged && nt == 1) { mask_block(S0, 0, 0); mask_block(S1, 0, 1); }
+    M = fmaxf(row_max(S0), row_max(S1)) - 7.0f;   // the first tile's largest P is 2^7 (tile 0 recomputes S1 under this shift)
+    set_negM();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S0[r] -= M;
+    mx0 = 7.0f;
+    if (nt > 1) { fr[2] = k_frag(1, 0, 0); fr[3] = k_frag(1, 0, 1); }
+
+    // ---- tiles 0 .. nt-1; the steady bodies are unrolled by the ring depth so that ring slots are immediates of the ds_reads
+    int t = 0;
+#pragma unroll 1
+    for (; t + 2 < nt; ++t) tile(t, SR{}, T_{}, T_{}, F_{}, F_{});       // steady tiles (two successors)
+    if (t + 1 < nt) {                             // second-last tile
+        if (ragged) tile(t, SR{}, T_{}, F_{}, F_{}, T_{}); else tile(t, SR{}, T_{}, F_{}, F_{}, F_{});
+        ++t;
+    }
+    if (ragged) tile(t, SR{}, F_{}, F_{}, T_{}, F_{}); else tile(t, SR{}, F_{}, F_{}, F_{}, F_{});       // last tile
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l
+    float l_tot;
+    if (VALU_SUM) l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    else l_tot = osum[0];                          // every accumulator register of the ones-MFMA holds this lane's query's row sum
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Lq) {
+        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * hi;
+                u32x2_t w = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv), pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
+                *(u32x2_t*)(dst + col) = w;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads,
@@ -523,8 +874,17 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
     p.q_scale_e8m0 = e | (e << 8) | (e << 16) | (e << 24);
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_fp8: grid too large"); return FW_E_BADARG; }
-    // FW_ATTN_VAR = 8: the in-phase kernel (A/B); default: the two-group ping-pong kernel
-    if (fw_get_option(FW_OPT_ATTN_VAR) == 8) hipLaunchKernelGGL(attention_fp8_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attention_fp8_pp_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    // default (round 5): the single-stream kernel with the row sums on the matrix pipe.  A/B arms by FW_ATTN_VAR: 8 = the in-phase
+    // kernel, 9 = the two-group ping-pong kernel (the round-2..4 default), 10 = single-stream with fp32 row sums on the vector pipe,
+    // 11 = single-stream with all eight waves in phase (no half-tile skew between the two waves of a SIMD).
+    // Views of 4 GiB or more do not fit the descriptors' 32-bit byte offsets: they keep the ping-pong kernel (pointer requests).
+    const int var = fw_get_option(FW_OPT_ATTN_VAR);
+    const bool big = (uint64_t)Lk * (uint64_t)ldk >= 0xffffffffull || (uint64_t)head_dim * (uint64_t)lkp >= 0xffffffffull ||
+                     (uint64_t)(Lk + 6 * KVB) * (uint64_t)ldk >= 0x7fffffffull;
+    if (var == 8) hipLaunchKernelGGL(attention_fp8_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    else if (var == 9 || big) hipLaunchKernelGGL(attention_fp8_pp_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    else if (var == 10) hipLaunchKernelGGL((attention_fp8_sp_kernel<1>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    else if (var == 11) hipLaunchKernelGGL((attention_fp8_sp_kernel<2>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_fp8_sp_kernel<0>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

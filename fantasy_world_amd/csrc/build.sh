@@ -13,9 +13,17 @@ pids=()
 names=()
 for f in gemm.hip gemm_pp.hip attention.hip elementwise.hip heads.hip fp8.hip gemm_fp8.hip attention_fp8.hip; do
   o="${here}/${f%.hip}.o"
-  if [ ! -f "$o" ] || [ "${here}/$f" -nt "$o" ] || [ "${here}/fw_common.h" -nt "$o" ] || [ "${here}/gemm_common.h" -nt "$o" ] || [ "${here}/../../include/fw_mi355x.h" -nt "$o" ]; then
-    rm -f "$o"
-    if [ "$f" = "fp8.hip" ]; then   # IEEE division for the fp8 quantiser: no -ffast-math
+  # rebuild decision by CONTENT, not by mtime (round 5: this container's clock stepped backwards by minutes mid-session, so edited
+  # sources were "older" than their objects and a renamed kernel silently kept its old object): hash of source + headers + this script
+  want="$(cat "${here}/$f" "${here}/fw_common.h" "${here}/gemm_common.h" "${here}/../../include/fw_mi355x.h" "${BASH_SOURCE[0]}" | sha256sum | cut -d' ' -f1) ${FW_ATTN_EXTRA_FLAGS-default}"
+  if [ ! -f "$o" ] || [ ! -f "$o.sha" ] || [ "$(cat "$o.sha")" != "$want" ]; then
+    rm -f "$o" "$o.sha"
+    echo "$want" > "$o.sha.new"
+    if [ "$f" = "fp8.hip" ] || [ "$f" = "elementwise.hip" ] || [ "$f" = "heads.hip" ]; then
+      # no -ffast-math: IEEE division for the fp8 quantiser; and (round 5) the row passes -- LayerNorm / RMSNorm statistics, RoPE,
+      # GroupNorm, the head activations -- are HBM-bound, so the flag bought nothing there while it let the compiler re-associate
+      # sums and replace divisions / rsqrt by approximations from one hipcc to the next (round 4 had to pin the LayerNorm statistics by
+      # hand after a re-association moved bits).  Only the MFMA files keep it (their epilogue transcendentals sit beside MFMAs).
       "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "${here}/$f" -o "$o" &
     elif [ "$f" = "attention.hip" ]; then
       # no SLP vectorisation: hipcc otherwise packs the softmax row sums into v_pk_add_f32 (an anti-lever beside MFMAs,
@@ -34,7 +42,8 @@ pids+=($!); names+=("api.cpp")
 objs+=("$o")
 fail=0
 for i in "${!pids[@]}"; do
-  if ! wait "${pids[$i]}"; then echo "build.sh: compiling ${names[$i]} FAILED" >&2; fail=1; fi
+  if ! wait "${pids[$i]}"; then echo "build.sh: compiling ${names[$i]} FAILED" >&2; fail=1; rm -f "${here}/${names[$i]%.*}.o.sha.new"
+  elif [ -f "${here}/${names[$i]%.*}.o.sha.new" ]; then mv "${here}/${names[$i]%.*}.o.sha.new" "${here}/${names[$i]%.*}.o.sha"; fi
 done
 [ "$fail" = 0 ] || exit 1
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"

@@ -2,7 +2,7 @@
 //
 // Three kernels (round 1 carried six; the superseded generations -- first 2-stage staggered kernel, 5-deep half-slab ring,
 // compiler-ordered four-wave kernel, first ping-pong kernel -- were removed in round 2, their numbers are in docs/history/DESIGN_r03.md section 4):
-//   gemm_bf16_pp2_kernel   256x256x64, 8 waves in two groups running LOAD || MFMA ping-pong: every big token-major GEMM (default)
+//   gemm_bf16_four_slot_kernel   256x256x64, 8 waves in two groups running LOAD || MFMA ping-pong: every big token-major GEMM (default)
 //   gemm_bf16_w4b_kernel   256x256x64, 4 waves with 128x128 wave tiles, hand-ordered single instruction stream: the INDEPENDENT
 //                          implementation the full-size agreement tests compare the default path with (FW_GEMM_KERNEL=5)
 //   gemm_bf16_kernel       128x128x64, 4 waves: small / ragged shapes and the <= 128-row M tail of the big ones
@@ -377,7 +377,7 @@ constexpr int TILE_TS_MAX = 8192;
 __device__ unsigned long long g_gemm_tile_ts[TILE_TS_MAX * 6];
 
 template <int TS, bool CONV>     // TS: 0 = product, 1 = TIMING build (phase + tile stamps), 2 = tile stamps only (does not perturb the loop)
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_four_slot_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
 
     const int tid = threadIdx.x;
@@ -819,13 +819,13 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (kern >= 6 && fw_launch_gemm_pp(p, kern, fw_get_option(FW_OPT_GEMM_VAR), st)) {
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
+            hipLaunchKernelGGL((gemm_bf16_four_slot_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 8) {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<3, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // run-time-stage loop + 16 VALU of ballast per slab
+            hipLaunchKernelGGL((gemm_bf16_four_slot_kernel<3, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // run-time-stage loop + 16 VALU of ballast per slab
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 4) {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<2, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // tile stamps only (run-time-stage loop)
+            hipLaunchKernelGGL((gemm_bf16_four_slot_kernel<2, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // tile stamps only (run-time-stage loop)
         } else {
-            hipLaunchKernelGGL((gemm_bf16_pp2_kernel<0, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);
+            hipLaunchKernelGGL((gemm_bf16_four_slot_kernel<0, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);
         }
         return (int)hipGetLastError();
     }
@@ -878,7 +878,7 @@ extern "C" int fw_conv_gemm_bf16(const uint16_t* x, int64_t ldx, int C, int T, i
     hipStream_t st = (hipStream_t)stream;
     if (big && K >= 4 * BK) {
         p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
-        hipLaunchKernelGGL((gemm_bf16_pp2_kernel<0, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, st, p);
+        hipLaunchKernelGGL((gemm_bf16_four_slot_kernel<0, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, st, p);
         return (int)hipGetLastError();
     }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;

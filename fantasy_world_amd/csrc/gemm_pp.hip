@@ -7,9 +7,9 @@ using namespace fwgemm;
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// Round 4: the ping-pong kernel with TWO slots per k-slab instead of four (gemm_bf16_pp4_kernel below is its final form).
+// Round 4: the ping-pong kernel with TWO slots per k-slab instead of four (gemm_bf16_two_slot_kernel below is its final form).
 //
-// What the phase timeline of gemm_bf16_pp2_kernel (gemm.hip) says (profiles/r02/gemm_timeline_call5.txt): a slab costs ~3100 cycles
+// What the phase timeline of gemm_bf16_four_slot_kernel (gemm.hip) says (profiles/r02/gemm_timeline_call5.txt): a slab costs ~3100 cycles
 // for 2048 cycles of MFMA; its four barrier-separated slots last 780 / 704 / 672 / 988 cycles against 512 of matrix work each: every
 // slot pays the barrier turn-around (the matrix pipe of a SIMD is idle from the last MFMA of one group until the first of the other)
 // and the LDS-DMA instructions issued from inside the bursts stall their wave with nobody else on the SIMD issuing MFMAs.  Here
@@ -30,7 +30,7 @@ namespace {
 #define FW_BLDS16(rs, voff, soff, ldsptr) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, FW_LDS_PTR(ldsptr), 16, voff, soff, 0, 0)
 
 // ---------------------------------------------------------------------------------------------------------------
-// gemm_bf16_pp4_kernel: the two-slot kernel with EVERY LDS-DMA piece issued from a LOAD phase and a third W stage.
+// gemm_bf16_two_slot_kernel: the two-slot kernel with EVERY LDS-DMA piece issued from a LOAD phase and a third W stage.
 //
 // gemm_bf16_pp3_kernel's measurements (profiles/r04/gemm_ab_call3_two_slot_kernel.txt): the more pieces leave the MFMA bursts the
 // faster it runs (A0A = 0 / 2 / 4: 1262 / 1317 / 1337 TF/s on the qkv shape).  What keeps the rest inside the bursts there is the
@@ -59,7 +59,7 @@ __device__ unsigned long long g_pp_ts[2 * 4 * 8];      // TIMING build: [group][
 // (Also measured and not kept: the accumulators pinned in the accumulation half of the register file through asm MFMAs with "+a"
 //  operands -- bit-identical, -0.7 %, profiles/r04/gemm_ab_call10_agpr_accumulators_no_gain.txt.)
 template <int TS>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp4_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_two_slot_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[P4_LDS];
 
     const int tid = threadIdx.x;
@@ -232,12 +232,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp4_kernel(GemmArgs p) {
 bool fw_launch_gemm_pp(const GemmArgs& p, int kern, int var, hipStream_t st) {
     if (kern != 9 || !(p.lda < (1 << 21) && p.ldw < (1 << 21))) return false;           // 32-bit byte offsets inside a tile
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(512);
-    if (var & 2) hipLaunchKernelGGL((gemm_bf16_pp4_kernel<1>), grid, block, 0, st, p);      // TIMING build
-    else hipLaunchKernelGGL((gemm_bf16_pp4_kernel<0>), grid, block, 0, st, p);
+    if (var & 2) hipLaunchKernelGGL((gemm_bf16_two_slot_kernel<1>), grid, block, 0, st, p);      // TIMING build
+    else hipLaunchKernelGGL((gemm_bf16_two_slot_kernel<0>), grid, block, 0, st, p);
     return true;
 }
 
-// Measurement hook (tools/gemm_pp_timeline.py): the phase stamps written by the TIMING build of gemm_bf16_pp4_kernel.
+// Measurement hook (tools/gemm_pp_timeline.py): the phase stamps written by the TIMING build of gemm_bf16_two_slot_kernel.
 extern "C" int fw_debug_gemm_pp_timestamps(unsigned long long* host_out, int n) {
     if (n <= 0 || n > 64) { fw_set_error("fw_debug_gemm_pp_timestamps: n out of range"); return FW_E_BADARG; }
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_ts), sizeof(unsigned long long) * n);

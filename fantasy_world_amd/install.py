@@ -114,6 +114,23 @@ class _WeightWatch:
                 if mod._parameters.get(leaf) is not None and mod._parameters[leaf].numel()]
         return torch.stack(vals).cpu() if vals else torch.zeros(0)
 
+    def sync(self, model, names):
+        """Names packed AFTER install (the geometry heads on the first return_prediction call, the pose encoder on the first
+        get_pose_fea) join the watch at the moment they were packed: called right after every engine call (the snapshot
+        taken at install time never saw them, so a later load_state_dict touching only the heads went unnoticed)."""
+        if len(names) == len(self.slots):
+            return
+        have = {n for n, _, _ in self.slots}
+        mods = dict(model.named_modules())
+        for name in names:
+            if name in have:
+                continue
+            owner, _, leaf = name.rpartition(".")
+            mod = mods[owner]
+            p = mod._parameters.get(leaf)
+            self.slots.append((name, mod, leaf))
+            self.signature.append((None, None) if p is None else (p.data_ptr(), p._version))
+
     def unchanged(self):
         return self._read() == self.signature
 
@@ -241,6 +258,10 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     else:
         engine = FusionEngine(cfg, get, ops, heads_cfg=heads_config_from_model(model.vggt),
                               cache_step_invariants=cache_step_invariants, precision=precision, shard=shard)
+    if engine.shard is not None and engine.shard.world > 1:
+        # the grouped q|k|v exchange is probed once on the side communicator, exactly as parallel.make_engine does for bench.py: a
+        # multi-GPU drop-in run of the reference script gets the same first-run safety
+        engine.exchange_groups = engine.shard.negotiate_exchange_groups(engine.exchange_groups, getattr(ops, "device", None) or "cpu")
     if release_reference_weights:
         if engine.heads_cfg is not None:
             engine.geometry_heads()                              # pack now: their source tensors are about to go
@@ -283,6 +304,7 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                                                  control_camera_latents_input=control_camera_latents_input))
         else:
             out, outputs = forward(context, return_prediction)
+        watch.sync(self, get.fetched)                # whatever this call packed lazily (geometry heads) is watched from here on
         if not return_prediction:
             return out, None
         if engine.heads_cfg is not None:
@@ -325,7 +347,8 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
                 return None
             if "enc" not in state:
                 from .pose_encoder import PoseEncoder
-                state["enc"] = PoseEncoder(dict(model_ref().named_parameters()).__getitem__, ops)
+                state["enc"] = PoseEncoder(get, ops)         # through the recording getter: released / watched like every packed name
+                watch.sync(model_ref(), get.fetched)
             return state["enc"].encode(plucker)
 
         cam_ref = weakref.ref(cam)

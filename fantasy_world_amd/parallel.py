@@ -168,8 +168,31 @@ class SequenceShard:
             secs = time.monotonic() - t0
             if not ok:
                 ran = 1
+                # a probe that really stalled leaves collectives -- device kernels under RCCL -- on the probe communicator: every later
+                # device-wide synchronize (bench.py's barrier) and the process-group watchdog would wait on them.  Abort that
+                # communicator NOW (ncclCommAbort ends its kernels); if it cannot be aborted the run is refused instead of hanging.
+                self._abandon_probe_group()
         self.exchange_probe = {"requested": int(requested), "ran": int(ran), "ok": bool(ok), "seconds": round(secs, 3)}
         return ran
+
+    def _abandon_probe_group(self):
+        """After a failed probe: end whatever is still in flight on the probe communicator so that nothing on this device waits for
+        it.  gloo (CPU tests, the several-ranks-on-one-GPU debugging aid): nothing runs on the device, nothing to do.  RCCL: abort the
+        communicator; a backend without abort() -> RuntimeError (a clear refusal beats a 900 s hang)."""
+        g, self.probe_group = self.probe_group, None
+        if g is None:
+            return "no probe communicator"
+        name = dist.get_backend(g)
+        if name != "nccl":
+            return f"{name}: nothing on the device"
+        try:
+            be = g._get_backend(torch.device("cuda"))
+            be.abort()
+        except Exception as e:
+            raise RuntimeError("the grouped head-exchange probe did not complete on this rank set and its RCCL communicator could not "
+                               f"be aborted ({e!r}): refusing to continue -- set FW_SP_EXCHANGE_GROUPS=1 to skip the probe") from e
+        self._probe_keepalive = None
+        return "nccl: probe communicator aborted"
 
     def _probe_grouped_exchange(self, device, timeout_s, rounds=4, rows=512, c=256):
         """The engine's own pattern (FusionEngine._dit_attn_begin / _dit_attn_mid), `rounds` blocks back to back on MB-sized bf16
@@ -407,6 +430,30 @@ def make_topology(rank, world, local=0, cfg_parallel=True, mode="sp", reduce_dty
     return Topology(rank, world, local, 1, 0, **inner(rank, world, groups_for(list(range(world)))))
 
 
+def reduce_dtype_from_env():
+    """FW_TP_REDUCE_DTYPE: dtype of the all-reduced partial sums of the tensor-parallel partition.  Default fp32, decided from the
+    parity data (tests/golden/parity_bounds_gpu.json `tp/world4/*`): with fp32 partial sums the sharded forward sits at the
+    unsharded one's distance from the fp32 golden (2.68e-3), with bf16 partial sums at 3.2e-3 -- +20 % error for half the bytes.
+    What the bytes cost is measured by bench.py at N > 1 (`comm.microbench`: the same [rows, 5120] all-reduce in both dtypes),
+    so the first hardware run records the price of this default next to it; bf16 stays one environment variable away."""
+    reduce_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(os.environ.get("FW_TP_REDUCE_DTYPE", "fp32"))
+    if reduce_dtype is None:
+        raise ValueError("FW_TP_REDUCE_DTYPE must be fp32 or bf16")
+    return reduce_dtype
+
+
+def alt_topology(topo):
+    """The OTHER partition over the same ranks (bench.py's `alt` block at N > 1: one hardware opportunity answers both partition
+    questions): tensor-parallel groups when `topo` is sequence-sharded and vice versa, same CFG split.  New
+    process groups are created (collective over the world: every rank must call this).  None when the ranks that share one
+    forward are a single rank (world 2 = two CFG groups of one GPU: both partitions are the unsharded forward)."""
+    if topo.world == 1 or topo.group_world == 1:
+        return None
+    mode = "sp" if topo.tp is not None else "tp"
+    return make_topology(topo.rank, topo.world, topo.local, cfg_parallel=topo.cfg_groups == 2, mode=mode,
+                         reduce_dtype=reduce_dtype_from_env())
+
+
 def init_topology(backend=None, cfg_parallel=True, mode=None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) -> Topology.
     mode: "sp" | "tp"; default from $FW_PARALLEL, else "sp"."""
@@ -416,14 +463,7 @@ def init_topology(backend=None, cfg_parallel=True, mode=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
         return Topology(local=local)
-    # FW_TP_REDUCE_DTYPE: dtype of the all-reduced partial sums of the tensor-parallel partition.  Default fp32, decided from the
-    # parity data (tests/golden/parity_bounds_gpu.json `tp/world4/*`): with fp32 partial sums the sharded forward sits at the
-    # unsharded one's distance from the fp32 golden (2.68e-3), with bf16 partial sums at 3.2e-3 -- +20 % error for half the bytes.
-    # What the bytes cost is measured by bench.py at N > 1 (`comm.microbench`: the same [rows, 5120] all-reduce in both dtypes),
-    # so the first hardware run records the price of this default next to it; bf16 stays one environment variable away.
-    reduce_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(os.environ.get("FW_TP_REDUCE_DTYPE", "fp32"))
-    if reduce_dtype is None:
-        raise ValueError("FW_TP_REDUCE_DTYPE must be fp32 or bf16")
+    reduce_dtype = reduce_dtype_from_env()
     if not dist.is_initialized():
         if backend is None:
             # "nccl" IS RCCL on ROCm.  FW_DIST_BACKEND=gloo: debugging aid for the CFG-parallel path only (several ranks sharing
@@ -466,8 +506,16 @@ def golden_self_check(topo, ops, case="wan21_cfg1_l2_f9_64x64", tol=8e-3, golden
     not print a throughput.  9 latent frames shard over up to 8 ranks."""
     import torch.distributed as dist
     from . import config as fwc, synth
-    gdir = golden_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
-    g = torch.load(os.path.join(gdir, case + ".pt"), map_location="cpu", weights_only=False)
+    # the default case ships INSIDE the package (fantasy_world_amd/golden/: meta + noise_pred of the tests/golden fixture, byte-checked by
+    # tests/test_multi_gpu_first_run_cpu.py) so that an installed package without the tests/ tree keeps its first-run check; any other
+    # case is looked up in the repository's tests/golden/.  A missing fixture RAISES: the check must never vanish silently.
+    here = os.path.dirname(os.path.abspath(__file__))
+    cands = [golden_dir] if golden_dir else [os.path.join(here, "golden"), os.path.join(os.path.dirname(here), "tests", "golden")]
+    path = next((os.path.join(d, case + ".pt") for d in cands if os.path.isfile(os.path.join(d, case + ".pt"))), None)
+    if path is None:
+        raise FileNotFoundError(f"golden_self_check: fixture {case}.pt not found in {cands}; the multi-rank first-run check cannot run "
+                                "(FW_BENCH_GOLDEN_CHECK=0 skips it deliberately)")
+    g = torch.load(path, map_location="cpu", weights_only=False)
     meta = g["meta"]
     cfg = (fwc.plumbing22 if meta.get("flavour") == "wan22" else fwc.plumbing)(**meta["cfg"])
     f, h2, w2 = meta["grid"]
@@ -517,13 +565,28 @@ def comm_microbench(topo, device, rows, width=5120, iters=3):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=group)
         return float(dt.item())
     out = {"rows": int(rows), "width": int(width), "ranks": int(n)}
-    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
-        t = torch.ones(rows, width, dtype=dt, device=device)
+    # everything that can fail on ONE rank (allocation) happens before the first collective, and whether to run is decided
+    # collectively (MIN of an ok flag): a rank that raised would otherwise leave the others blocked in the all-reduce
+    bufs, err = {}, None
+    try:
+        if os.environ.get("FW_COMM_MICROBENCH_FORCE_FAIL") == str(topo.rank):       # test hook
+            raise MemoryError("forced")
+        for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+            bufs[name] = torch.ones(rows, width, dtype=dt, device=device)
+        r = rows // n
+        bufs["src"] = torch.ones(n * r, 3 * width // n, dtype=torch.bfloat16, device=device)
+        bufs["dst"] = torch.empty_like(bufs["src"])
+    except Exception as e:
+        err = repr(e)[:200]
+    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        return {"error": err or "another rank of the group could not allocate the buffers", "rows": int(rows), "ranks": int(n)}
+    for name in ("bf16", "fp32"):
+        t = bufs[name]
         out[f"all_reduce_{name}_ms"] = timed(lambda: dist.all_reduce(t, group=group))
         out[f"all_reduce_{name}_bytes"] = t.numel() * t.element_size()
-    r = rows // n
-    src = torch.ones(n * r, 3 * width // n, dtype=torch.bfloat16, device=device)
-    dst = torch.empty_like(src)
+    src, dst = bufs["src"], bufs["dst"]
     out["all_to_all_qkv_bf16_ms"] = timed(lambda: dist.all_to_all_single(dst, src, group=group))
     out["all_to_all_qkv_bf16_bytes"] = src.numel() * 2
     return out

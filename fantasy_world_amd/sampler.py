@@ -67,6 +67,14 @@ def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cf
     step-invariant cache is off or already warm (its entries are produced on the stream that first asks for them)."""
     t = scheduler.timestep_on(step_id, latents.device, latents.dtype)
     if cfg_streams and (topo is None or topo.world == 1) and latents.is_cuda:
+        # The engine fills shared state lazily on whichever stream asks first (rotary tables per grid, the all-zero verdict of the
+        # Pluecker features, lazily packed heads, step-invariant cache entries): the first step on a grid therefore runs on ONE stream
+        # and only later steps fork (ADVICE r04: a cold two-stream step could read a table the other stream was still writing).
+        key = tuple(latents.shape)
+        if getattr(engine, "_cfg_streams_warm", None) != key:
+            engine._cfg_streams_warm = key
+            cfg_streams = False
+    if cfg_streams and (topo is None or topo.world == 1) and latents.is_cuda:
         cur, side = torch.cuda.current_stream(latents.device), _side_stream(latents.device)
         side.wait_stream(cur)                                 # inputs (latents, timestep, conditioning) were produced on `cur`
         with torch.cuda.stream(side):

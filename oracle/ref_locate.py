@@ -9,8 +9,10 @@ Resolution order:
                                                .so files do.  Extracted once per machine into a scratch directory.)
 Nothing under fantasy_world_amd/ imports this file; with none of the three present the callers skip (tests) or fall back to the
 oracle restatement (bench.py's cpu_baseline leg, kind = "port")."""
+import atexit
 import hashlib
 import os
+import shutil
 import tarfile
 import tempfile
 
@@ -65,9 +67,23 @@ def reference_root():
                 f.write(tag)
             try:
                 os.rename(tmp, dst)
-            except OSError:                 # another process of this user won the race (or a stale directory is in the way)
-                if not _trusted(dst, tag):
-                    dst = tmp               # use the private extraction itself
+            except OSError:                 # another process of this user won the race, or a stale / untrusted directory is in the way
+                if _trusted(dst, tag):
+                    shutil.rmtree(tmp, ignore_errors=True)          # the winner's copy is good: drop ours
+                else:
+                    # an untrusted leftover (partial extraction, wrong mode): move it aside when it is ours and retry once, so the cache
+                    # heals instead of growing by one bundle copy per run
+                    try:
+                        if os.lstat(dst).st_uid == os.getuid():
+                            aside = tempfile.mkdtemp(prefix=f"{tag}_stale_", dir=base)
+                            os.rename(dst, os.path.join(aside, "d"))
+                            shutil.rmtree(aside, ignore_errors=True)
+                            os.rename(tmp, dst)
+                    except OSError:
+                        pass
+                    if not _trusted(dst, tag):
+                        dst = tmp           # use the private extraction itself, and remove it when this process ends
+                        atexit.register(shutil.rmtree, tmp, ignore_errors=True)
         if _trusted(dst, tag):
             _cached = dst
             return dst

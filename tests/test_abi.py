@@ -103,7 +103,7 @@ def test_hot_kernels_do_not_spill():
         pytest.skip("ROCm LLVM tools not found")
     table = {name.replace("void ", ""): (vg, ag, lds, scr) for _, name, vg, ag, lds, scr in kernel_resources.all_kernels()}
     must_be_clean = ["attention_sp_kernel<128, 65>", "attention_sp_kernel<128, 1>", "attention_sp_kernel<64, 1>", "attention_sp_kernel<96, 1>",
-                     "attention_pp3_kernel<96, 0>", "gemm_bf16_pp4_kernel<0>", "gemm_bf16_pp2_kernel<0, false>", "gemm_bf16_pp2_kernel<0, true>",
+                     "attention_pp3_kernel<96, 0>", "gemm_bf16_two_slot_kernel<0>", "gemm_bf16_four_slot_kernel<0, false>", "gemm_bf16_four_slot_kernel<0, true>",
                      "gemm_fp8_pp_kernel", "layernorm_lds_kernel<20, false, true>", "layernorm_lds_kernel<20, true, false>",
                      "layernorm_lds_kernel<4, true, true>", "qk_prep_wave_kernel<10, 1, 1>"]
     for k in must_be_clean:

@@ -58,3 +58,28 @@ def test_bench_tensor_parallel_mode_by_environment():
     par = out["config"]["parallelism"]
     assert "CFG-parallel x2" in par and "tensor-parallel x4" in par and "sequence-sharded" not in par
     assert {"all_reduce", "all_gather_rows", "all_gather_cfg"} <= set(out["comm"]["by_kind"])
+
+
+@pytest.mark.parametrize("mode", ["sp", "tp"])
+def test_bench_alt_block_runs_the_other_partition_in_the_same_process_group(mode):
+    """N > 1: after the headline loop the OTHER partition (tensor-parallel when the headline is the CFG x sequence-shard default, and vice
+    versa) runs over the same ranks and lands in an `alt` block beside the headline; dry run = its process groups
+    and collectives."""
+    out = _run(8, env_extra={"FW_PARALLEL": mode})
+    par, alt = out["config"]["parallelism"], out["alt"]
+    assert ("sequence-sharded x4" in par) == (mode == "sp") and ("tensor-parallel x4" in par) == (mode == "tp")
+    assert "CFG-parallel x2" in alt["parallelism"]
+    assert ("tensor-parallel x4" in alt["parallelism"]) == (mode == "sp") and ("sequence-sharded x4" in alt["parallelism"]) == (mode == "tp")
+    kinds = set(alt["comm"]["by_kind"])
+    assert "all_gather_cfg" in kinds and (("all_reduce" in kinds) if mode == "sp" else ("all_gather_rows" in kinds))
+
+
+def test_bench_alt_block_absent_where_both_partitions_are_the_unsharded_forward():
+    assert "alt" not in _run(2)            # two CFG groups of one GPU each
+    assert "alt" not in _run(4, env_extra={"FW_BENCH_ALT": "0"})
+
+
+def test_bench_alt_block_cannot_cost_the_headline_line():
+    """A second partition that never finishes: the guard prints the headline line with alt = the error and every rank exits 0."""
+    out = _run(4, env_extra={"FW_BENCH_ALT_FORCE_HANG": "1", "FW_BENCH_ALT_BUDGET_S": "3"})
+    assert out["n_gpus"] == 4 and "did not finish" in out["alt"]["error"] and "comm" in out

@@ -121,3 +121,17 @@ def test_first_run_environment_and_watchdog_defaults(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "2")
     with pytest.raises((ValueError, RuntimeError)):
         parallel.init_topology(backend="gloo")
+
+
+def test_packaged_golden_is_the_repository_fixture():
+    """fantasy_world_amd/golden/ ships the default case of golden_self_check inside the package: it must be the
+    tests/golden fixture's meta + noise_pred, and a missing fixture must raise instead of skipping the check."""
+    import pytest
+    from fantasy_world_amd import parallel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    case = "wan21_cfg1_l2_f9_64x64"
+    a = torch.load(os.path.join(root, "fantasy_world_amd", "golden", case + ".pt"), map_location="cpu", weights_only=False)
+    b = torch.load(os.path.join(root, "tests", "golden", case + ".pt"), map_location="cpu", weights_only=False)
+    assert a["meta"] == b["meta"] and torch.equal(a["noise_pred"], b["noise_pred"])
+    with pytest.raises(FileNotFoundError):
+        parallel.golden_self_check(None, None, case="no_such_case")
