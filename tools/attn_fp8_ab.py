@@ -34,6 +34,9 @@ for L in (32760, 111600):
     qs = (q.float() * ops.q_scale(hd)).to(torch.bfloat16)
     vt = ops.prepare_v(v, H, hd)
     arms = {"fp8 ping-pong (var 9)": 9, "fp8 single-stream, in phase (var 11)": 11, "fp8 single-stream, half-tile skew (default)": 192}
+    for extra in os.environ.get("EXTRA_VARS", "").split(","):
+        if extra:
+            arms[f"fp8 experiment var {extra}"] = int(extra)
     outs, times = {}, {n: [] for n in list(arms) + ["bf16 kernel"]}
     for name, var in arms.items():
         ops.set_option("attn_var", var)

@@ -21,7 +21,7 @@ for st in "${LIST[@]}"; do
     bench)
       timeout ${T_BENCH:-1200} python bench.py ${arg:---steps 2 --warmup 1} > $O/bench_$TAG.log 2>&1; tail -1 $O/bench_$TAG.log | cut -c1-600 ;;
     trace)
-      rm -rf $O/prof; ( cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline $arg > $O/prof_bench_$TAG.log 2>&1 )
+      rm -rf $O/prof; ( cd /tmp; export FW_BENCH_DROPIN=0; timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline $arg > $O/prof_bench_$TAG.log 2>&1 )
       for db in $(find $O/prof -name '*.db'); do python tools/rocpd_summary.py $db --top 70 --split > $O/rocprof_kernel_stats_bench_$TAG.txt 2>&1; done
       rm -rf $O/prof; head -40 $O/rocprof_kernel_stats_bench_$TAG.txt | cut -c1-150 ;;
     pmc)
