@@ -74,7 +74,10 @@ int fw_abi_version(void);
                                    ring slots (the round-2 default); 131 / 195 = the same two with one 64-row wave per SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
                                    WITHOUT the pre-scaled flag get).  Bits 8-9 (added to any of the above): static wave priority
                                    before the tile loop, 256 = waves 4..7, 512 = waves 0..3 (measured +-0, default off).
-                                   fw_attention_fp8: 8 = its in-phase kernel, anything else = its two-group ping-pong kernel */
+                                   fw_attention_fp8 (round 5): default = the single-stream kernel (row sums by a ones-MFMA, the two waves
+                                   of a SIMD half a tile apart); 8 = the round-2 in-phase kernel, 9 = the two-group ping-pong kernel
+                                   (rounds 2-4 default; also serves views of 4 GiB or more), 10 = single stream with fp32 row sums
+                                   on the vector pipe, 11 = single stream with all eight waves in phase */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
 
