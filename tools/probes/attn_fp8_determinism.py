@@ -6,7 +6,8 @@ from fantasy_world_amd.hip_ops import HipOps
 ops = HipOps("cuda:0")
 g = torch.Generator(device="cuda").manual_seed(3)
 hd, H = 128, 8
-for Lq, Lk in ((4096, 4100), (32760, 32760)):
+REPS = int(os.environ.get('REPS', 5))
+for Lq, Lk in ((4096, 4100), (32760, 32760)) + (((111600, 111600),) if os.environ.get('BIG') else ()):
     q = torch.randn(Lq, H * hd, device="cuda", generator=g).to(torch.bfloat16)
     k = torch.randn(Lk, H * hd, device="cuda", generator=g).to(torch.bfloat16)
     v = torch.randn(Lk, H * hd, device="cuda", generator=g).to(torch.bfloat16)
@@ -16,9 +17,9 @@ for Lq, Lk in ((4096, 4100), (32760, 32760)):
     qs = ops.qk_prep(q.clone(), H, hd, out_scale=ops.q_scale(hd))
     for var, name in ((192, "fp8 single-stream (default)"), (11, "fp8 single-stream in phase"), (9, "fp8 ping-pong")):
         ops.set_option("attn_var", var)
-        runs = [ops.attention_fp8(q8, k8, vt8, H, hd, lk).float() for _ in range(5)]
+        runs = [ops.attention_fp8(q8, k8, vt8, H, hd, lk) for _ in range(REPS)]
         torch.cuda.synchronize()
-        print(f"Lq {Lq} Lk {Lk} {name}: elements differing from run 0: {[int((runs[0] != r).sum()) for r in runs[1:]]}")
+        print(f"Lq {Lq} Lk {Lk} {name}: runs differing from run 0: {sum(int(not torch.equal(runs[0], r)) for r in runs[1:])} of {len(runs) - 1}")
     ops.set_option("attn_var", 192)
-    runs = [ops.attention(qs, k, v, H, hd, q_prescaled=True).float() for _ in range(5)]
-    print(f"Lq {Lq} Lk {Lk} bf16 kernel (default): elements differing from run 0: {[int((runs[0] != r).sum()) for r in runs[1:]]}")
+    runs = [ops.attention(qs, k, v, H, hd, q_prescaled=True) for _ in range(REPS)]
+    print(f"Lq {Lq} Lk {Lk} bf16 kernel (default): runs differing from run 0: {sum(int(not torch.equal(runs[0], r)) for r in runs[1:])} of {len(runs) - 1}")
