@@ -63,5 +63,10 @@ for rep in range(3):
     for _ in range(4): ops.attention(k96s, q96r, q96r, 12, 96, q_prescaled=True)
     for _ in range(4): ops.attention(q64, k64, v64, 16, 64, q_prescaled=True)
     for _ in range(4): ops.attention_fp8(q8, k8, vt8, 8, 128, lk8)
+# round 5: the fp8 GEMM (qkv shape) and the new fp8 attention kernel as well
+lin8 = ops.pack_linear_fp8(w.contiguous(), torch.zeros(15360, device="cuda"))
+xq = ops.quantize_fp8_rows(x)
+for rep in range(3):
+    for _ in range(4): ops.linear(xq, lin8, out=out)
 torch.cuda.synchronize()
 ops.set_option("gemm_kernel", 9)
