@@ -20,7 +20,7 @@ leg runs for BOTH flavours by default, the checker's attention runs head chunk b
 does not fit FAILS the test (FW_FULL_DEPTH_HEADLINE_OPTIONAL=1 turns that into a recorded note; FW_FULL_DEPTH_HEADLINE=0 skips the leg;
 FW_FULL_DEPTH_CONFIG4=1 adds the Wan2.2 81f x 720p grid, L = 75 600, minutes of fp32 reference time).
 
-Round 5 also: (i) the bf16-rounding YARDSTICK at this depth -- the engine's own host code on torch ops with activations rounded to bf16
+Round 5 also: (i) the bf16-rounding YARDSTICK at this depth (opt-in, FW_FULL_DEPTH_YARDSTICK=1) -- the engine's own host code on torch ops with activations rounded to bf16
 where the HIP path stores bf16 (oracle/ref_ops.py:TorchRefOps(emulate_bf16=True)) against the same fp32 reference, 40 / 24 / 24 blocks,
 L = 8190 -- recorded next to the HIP path's numbers (the "floor" docs/parity.md quotes was an 8-block CPU number until now);
 (ii) test_full_depth_fp8_*: BASELINE configs[4]'s arithmetic ("fp8 attention + FFN") at the benchmarked depth.
@@ -191,7 +191,8 @@ def test_full_depth_model_matches_reference(flavour, parity):
         for name, ins in inputs.items():
             with_pred = name.startswith("small")
             got = _hip_forward(model, eng, cfg, ins, with_pred)
-            keep = want[name] if (flavour == "wan21" and name == YARDSTICK_GRID) else want.pop(name)
+            keep = want[name] if (flavour == "wan21" and name == YARDSTICK_GRID and
+                                  os.environ.get("FW_FULL_DEPTH_YARDSTICK", "0") == "1") else want.pop(name)
             hip_rows[name] = _compare(f"full_depth/{flavour}/{name}", parity, keep, got, cfg, with_pred)
             # and through the rebound method itself (B1), the call the reference's loop makes
             out, pred = model.joint_forward(ins["x"], **_kwargs(cfg, ins, False))
@@ -201,7 +202,9 @@ def test_full_depth_model_matches_reference(flavour, parity):
         uninstall(model)
     del eng
     torch.cuda.empty_cache()
-    if flavour == "wan21" and os.environ.get("FW_FULL_DEPTH_YARDSTICK", "1") == "1":
+    # opt-in (FW_FULL_DEPTH_YARDSTICK=1; ~40 s of fp32 torch ops and 74 GB more of weights): measured in round 5 -- floor 3.008e-3, HIP
+    # 3.018e-3 (profiles/r05/parity_call1_full_depth.json, docs/parity.md); the default run keeps the suite's wall time where it was
+    if flavour == "wan21" and os.environ.get("FW_FULL_DEPTH_YARDSTICK", "0") == "1":
         _yardstick(model, cfg, inputs[YARDSTICK_GRID], want.pop(YARDSTICK_GRID), hip_rows[YARDSTICK_GRID], parity)
 
 
@@ -251,7 +254,10 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
     cfg, model = _build("wan22")
     ops = HipOps(DEV)
     inputs, want32 = {}, {}
-    for name, (f, h2, w2) in GRIDS.items():
+    # the grid whose token count puts every GEMM / attention on the production kernels; FW_FULL_DEPTH_FP8_SMALL=1 adds the 144-token
+    # grid (measured in round 5: 1.51e-2 / 1.55e-2, the same plateau)
+    grids = {k: v for k, v in GRIDS.items() if k.startswith("production") or os.environ.get("FW_FULL_DEPTH_FP8_SMALL", "0") == "1"}
+    for name, (f, h2, w2) in grids.items():
         inputs[name] = synth.make_inputs(cfg, f, h2, w2, seed=11, device=DEV, dtype=torch.float32)
         want32[name] = _reference_forward(model, cfg, inputs[name], False)
 
