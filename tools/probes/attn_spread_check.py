@@ -1,4 +1,7 @@
 #!/usr/bin/env python
+# NOTE (round 5): this probe ran against an EXPERIMENTAL build of attention_sp_kernel (softmax spread over both stages, FW_ATTN_VAR bit 11 /
+# bit 12) that was measured and not adopted -- the kernel source in the tree is the round-4 schedule, where these FW_ATTN_VAR bits select
+# nothing.  Kept as the record of what profiles/r05/attn_spread_softmax_experiment_calls11_18.txt measured (docs/kernels.md).
 """Round-5 probe: the spread-softmax arm of attention_sp_kernel (FW_ATTN_VAR + 2048) against the default arm and against an fp32 softmax,
 on shapes that hit every loop exit (1, 2, 3, 5, 9 tiles; ragged and exact last tiles; batches; hd 128 and 64)."""
 import math, os, sys, torch

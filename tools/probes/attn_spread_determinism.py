@@ -1,3 +1,6 @@
+# NOTE (round 5): this probe ran against an EXPERIMENTAL build of attention_sp_kernel (softmax spread over both stages, FW_ATTN_VAR bit 11 /
+# bit 12) that was measured and not adopted -- the kernel source in the tree is the round-4 schedule, where these FW_ATTN_VAR bits select
+# nothing.  Kept as the record of what profiles/r05/attn_spread_softmax_experiment_calls11_18.txt measured (docs/kernels.md).
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from fantasy_world_amd.hip_ops import HipOps
