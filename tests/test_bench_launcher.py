@@ -83,3 +83,17 @@ def test_bench_alt_block_cannot_cost_the_headline_line():
     """A second partition that never finishes: the guard prints the headline line with alt = the error and every rank exits 0."""
     out = _run(4, env_extra={"FW_BENCH_ALT_FORCE_HANG": "1", "FW_BENCH_ALT_BUDGET_S": "3"})
     assert out["n_gpus"] == 4 and "did not finish" in out["alt"]["error"] and "comm" in out
+
+
+def test_bench_matrix_pipe_blocks_are_stored_measurements_with_provenance():
+    """`roofline.matrix_pipe` / `kernels.*.matrix_pipe` (round 5, replaces the `roofline_cap` model the round-4 counters contradicted) are
+    STORED counter measurements: every head size the headline runs has one, it names the profile it comes from, and the fraction it
+    predicts is busy x clock / 2.4 GHz."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for hd in (128, 96, 64):
+        m = bench.attention_measured(hd)
+        assert m is not None and 0.3 < m["mfma_busy"] < 1.0 and 1.0 < m["sustained_ghz"] < 2.4
+        assert "stored PMC pass" in m["source"] and "profiles/r0" in m["source"]
+        assert abs(m["predicted_frac_of_2p5_pf"] - m["mfma_busy"] * m["sustained_ghz"] / 2.4) < 1e-3
+    assert bench.attention_measured(80) is None          # no measurement, no number
