@@ -43,6 +43,31 @@ if ROOT not in sys.path:
 MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md chip table
 MFMA_FP8_PEAK = 5.0e15       # dense fp8 MFMA peak, same table
 
+# PREDICTED step time (ms, best .. worst) of the HEADLINE workload per (N, partition), communication included -- tools/predict_scaling.py,
+# profiles/r05/scaling_prediction.txt: one-GPU shard emulation + counted bytes / assumed xGMI link rates.  NOT a measurement: printed
+# beside the measured value of an N > 1 run so that the first SCALE_r*.json interprets itself.
+PREDICTED_STEP_MS = {(2, "sp"): (1729, 1729), (2, "tp"): (1729, 1729), (4, "sp"): (918, 1034), (4, "tp"): (1356, 2489),
+                     (8, "sp"): (492, 521), (8, "tp"): (778, 1344)}
+
+
+def predicted_block(n, mode, headline):
+    if not headline or (n, mode) not in PREDICTED_STEP_MS:
+        return None
+    best, worst = PREDICTED_STEP_MS[(n, mode)]
+    return {"step_ms_best": best, "step_ms_worst": worst, "value_best": 1e3 / best, "value_worst": 1e3 / worst,
+            "source": "PREDICTION, not a measurement: profiles/r05/scaling_prediction.txt (tools/predict_scaling.py; tp with fp32 partial sums)"}
+
+
+def alt_budget_s(t_build_s, ms_per_step, n_alt, n_experts):
+    """How long the second partition's block may take before the headline line is printed without it: $FW_BENCH_ALT_BUDGET_S, or scaled
+    with what THIS run measured -- two engine builds' worth (build + golden self-check engine), and the alt loop priced at 12x the
+    headline's step time (the predicted worst case of the other partition is 2.6x the default's; warm-up steps included) -- never
+    below 420 s.  Config 4 / 5 builds (two experts, 720p) need more than the flat 420 s of round 5."""
+    env = os.environ.get("FW_BENCH_ALT_BUDGET_S")
+    if env:
+        return float(env)
+    return max(420.0, 120.0 + 4.0 * t_build_s + 12.0 * (n_alt + n_experts) * ms_per_step / 1e3)
+
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -69,6 +94,10 @@ def parse_args(argv=None):
                          "streams (sampler.denoise_step(cfg_streams=True)) -- reported in a `cfg_streams` block, never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=45.0, help="bound on the CPU baseline sample")
+    ap.add_argument("--parallel", choices=["sp", "tp"], default=None,
+                    help="N > 1: how the ranks of a CFG group share ONE forward -- sp = sequence shard with head all-to-all (default), tp = "
+                         "north_star's attention-head / FFN-column tensor parallelism with all-reduce.  Overrides $FW_PARALLEL (a driver that "
+                         "cannot set environment variables can still choose); the other partition is timed in the `alt` block either way")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / topology / collective check without a GPU: no engine, no metric (value = null)")
     return ap.parse_args(argv)
@@ -156,7 +185,7 @@ def dry_run(args):
     import torch
     import torch.distributed as dist
     from fantasy_world_amd import parallel
-    topo = parallel.init_topology(backend="gloo")
+    topo = parallel.init_topology(backend="gloo", mode=args.parallel)
     stats = parallel.enable_comm_stats()
     sh = topo.shard
     F, hw, heads, hd = 8, 6, 8, 4
@@ -191,14 +220,17 @@ def dry_run(args):
             "value": None, "unit": "denoise-steps/s", "n_gpus": topo.world, "steps": args.steps,
             "warmup": args.warmup, "dry_run": True, "wall_s": float(tt.item()),
             "config": {"workload": "dry run", "parallelism": topo.describe()},
+            "predicted": predicted_block(topo.world, topo.mode, True),
             "comm": stats.summary(args.warmup + args.steps)}
     # the `alt` block of a real N > 1 run: the OTHER partition's groups over the same ranks, its collectives, under the same guard
     if os.environ.get("FW_BENCH_ALT", "1") != "0":
         topo2 = parallel.alt_topology(topo)
         if topo2 is not None:
-            guard = _AltGuard(line, topo.rank, float(os.environ.get("FW_BENCH_ALT_BUDGET_S", "120")))
-            stats.records.clear()
             n_alt = max(1, min(args.steps, int(os.environ.get("FW_BENCH_ALT_STEPS", "5"))))
+            # the real run scales the guard with what it measured (alt_budget_s); a dry run has measured nothing: floor 120 s here
+            budget = float(os.environ.get("FW_BENCH_ALT_BUDGET_S", "120"))
+            guard = _AltGuard(line, topo.rank, budget)
+            stats.records.clear()
             t1 = time.time()
             if os.environ.get("FW_BENCH_ALT_FORCE_HANG") == "1":       # test hook: the alt loop never finishes
                 time.sleep(3600)
@@ -217,7 +249,7 @@ def dry_run(args):
             dist.barrier()
             guard.cancel()
             line["alt"] = {"parallelism": topo2.describe(), "value": None, "steps": n_alt, "wall_s": time.time() - t1,
-                           "comm": stats.summary(n_alt)}
+                           "budget_s": budget, "predicted": predicted_block(topo.world, topo2.mode, True), "comm": stats.summary(n_alt)}
     if topo.rank == 0:
         print(json.dumps(line), flush=True)
     if topo.world > 1:
@@ -248,7 +280,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(wd, exit=True)
 
-    topo = parallel.init_topology()
+    topo = parallel.init_topology(mode=args.parallel)           # None: $FW_PARALLEL, else "sp"
     shard, rank, world, local = topo.shard, topo.rank, topo.world, topo.local
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -269,7 +301,7 @@ def main():
     # throughput (value = null, exit code 3).  FW_BENCH_GOLDEN_CHECK=0 skips it.
     golden = None
     if world > 1 and os.environ.get("FW_BENCH_GOLDEN_CHECK", "1") != "0":
-        golden = parallel.golden_self_check(topo, ops)
+        golden = parallel.golden_self_check(topo, ops, precision=args.precision, fp8_attention=args.fp8_attention)
         if not golden["ok"]:
             if rank == 0:
                 print(json.dumps({"metric": "denoise-steps/sec (81x480x832 latents, 14B WanDiT + IRG + VGGT branch)", "value": None,
@@ -339,7 +371,9 @@ def main():
         stats.records.clear()
     ops.start_kernel_timing({
         "attn_hd128_self": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] >= L,
-        "attn_hd128_cross": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] < 1024,
+        # cross-attention: one tag per key count (512 text keys / 257 CLIP image keys), so each carries its own FLOPs
+        "attn_hd128_cross_text": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] == 512,
+        "attn_hd128_cross_image": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] < 512,
         "attn_hd96_bicross_dit_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] >= L2,
         "attn_hd96_bicross_vggt_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] < L2,
         # frame vs global by the key count (P keys per frame vs all L2 tokens): the merged CFG pass runs both with batch > 1
@@ -410,7 +444,7 @@ def main():
     attn_ms, attn_n = timed["attn_hd128_self"]
     achieved = attn_flops / (attn_ms * 1e-3) if attn_n else 0.0
     Ll, L2l = L / sp, L2 / sp
-    kflops = {"attn_hd128_cross": None,      # two launches of different Lk (512 / 257) share the tag: reported as time only
+    kflops = {"attn_hd128_cross_text": nb * 4.0 * Ll * 512 * cfg.dim, "attn_hd128_cross_image": nb * 4.0 * Ll * Li * cfg.dim,
               "attn_hd96_bicross_dit_queries": nb * 4.0 * Ll * L2 * cfg.bicross_dim,
               "attn_hd96_bicross_vggt_queries": nb * 4.0 * L2l * L * cfg.bicross_dim,
               "attn_hd64_global": nb * 4.0 * L2 * L2 * cfg.vggt_dim / sp,
@@ -426,7 +460,9 @@ def main():
         kernels[name] = {"avg_launch_ms": ms, "launches_timed": n,
                          "tflops": None if fl is None else fl / (ms * 1e-3) / 1e12,
                          "frac_of_bf16_peak": None if fl is None else fl / (ms * 1e-3) / MFMA_BF16_PEAK}
-        if name.startswith("attn_hd") and fl is not None:
+        if args.precision == "fp8" and name.startswith("gemm_") and fl is not None:
+            kernels[name]["frac_of_fp8_peak"] = fl / (ms * 1e-3) / MFMA_FP8_PEAK      # the DiT blocks' linears run e4m3 x e4m3
+        if name.startswith("attn_hd") and fl is not None and "cross" not in name:
             kernels[name]["matrix_pipe"] = attention_measured(int(name[7:].split("_")[0]))
     # HBM-side traffic of the dominant kernel: measured with rocprofv3 PMC counters in separate passes (FETCH_SIZE, WRITE_SIZE)
     # as MI355X_MICROARCH.md prescribes, recorded under profiles/ with provenance; bench.py only reports the stored measurement
@@ -469,14 +505,19 @@ def main():
         "roofline": {"bound": "mfma", "kernel": ("attention_fp8_sp_kernel<0>" if fp8_attn else "attention_sp_kernel<128, 65>") + " (DiT self-attention, one launch per block"
                                + ("" if n_groups == 1 else f", in {n_groups} head groups under the sequence shard")
                                + ("" if topo.tp is None else f", {cfg.num_heads // sp} of {cfg.num_heads} heads per tensor-parallel rank") + ")",
-                     "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / MFMA_BF16_PEAK, "launches_timed": attn_n, "avg_launch_ms": attn_ms,
+                     # peak / frac follow the DOMINANT KERNEL's arithmetic type: the e4m3 attention kernel is priced against the dense
+                     # fp8 MFMA peak (5 PF), the bf16 kernel against 2.5 PF; frac_of_bf16_peak stays as a separate key for comparison
+                     "achieved": achieved / 1e12, "peak": (MFMA_FP8_PEAK if fp8_attn else MFMA_BF16_PEAK) / 1e12, "unit": "TFLOP/s",
+                     "frac": achieved / (MFMA_FP8_PEAK if fp8_attn else MFMA_BF16_PEAK), "frac_of_bf16_peak": achieved / MFMA_BF16_PEAK,
+                     "kernel_dtype": "fp8_e4m3" if fp8_attn else "bf16", "launches_timed": attn_n, "avg_launch_ms": attn_ms,
                      "flops_per_launch": attn_flops, "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/*/pmc_traffic.json)",
                      "algorithmic_bytes_per_launch": nb * 4.0 * L * cfg.dim * 2 / sp / n_groups,
                      "matrix_pipe": None if fp8_attn else attention_measured(cfg.head_dim)},
         "kernels": kernels,
     }
+    if world > 1:
+        out["predicted"] = predicted_block(world, topo.mode, headline)
     if dropin is not None:
         out["value_dropin"] = dropin["value"]
         out["dropin"] = dropin
@@ -540,7 +581,7 @@ def main():
     # headline ran the CFG x sequence-shard default, and vice versa) in the same process group, a shorter loop, printed as `alt` beside
     # the headline `value`: the first hardware run then answers both partition questions.  Guarded: if it does not
     # finish inside FW_BENCH_ALT_BUDGET_S the headline line is printed without it.  FW_BENCH_ALT=0 skips it.
-    if world > 1 and os.environ.get("FW_BENCH_ALT", "1") != "0" and not fp8_attn:
+    if world > 1 and os.environ.get("FW_BENCH_ALT", "1") != "0":
         topo2 = parallel.alt_topology(topo)
         if topo2 is not None:
             out["watchdog_s"] = wd
@@ -548,19 +589,21 @@ def main():
                 out["golden_check"] = golden
             if wd > 0:
                 faulthandler.cancel_dump_traceback_later()             # the guard below owns the clock from here
-            guard = _AltGuard(out, rank, float(os.environ.get("FW_BENCH_ALT_BUDGET_S", "420")))
-            alt = {"parallelism": topo2.describe()}
+            n_alt = max(1, min(args.steps, int(os.environ.get("FW_BENCH_ALT_STEPS", "5"))))
+            budget = alt_budget_s(t_build, 1e3 * dt / args.steps, n_alt, n_experts)
+            guard = _AltGuard(out, rank, budget)
+            alt = {"parallelism": topo2.describe(), "budget_s": round(budget, 1), "predicted": predicted_block(world, topo2.mode, headline)}
             try:
                 if os.environ.get("FW_BENCH_GOLDEN_CHECK", "1") != "0":
-                    alt["golden_check"] = parallel.golden_self_check(topo2, ops)
+                    alt["golden_check"] = parallel.golden_self_check(topo2, ops, precision=args.precision, fp8_attention=args.fp8_attention)
                 if alt.get("golden_check", {"ok": True})["ok"]:
                     t0 = time.time()
                     engines2 = [parallel.make_engine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s),
-                                                     ops, topo2, cache_step_invariants=args.cache_invariants, precision=args.precision)
+                                                     ops, topo2, cache_step_invariants=args.cache_invariants, precision=args.precision,
+                                                     **({"fp8_attention": True} if args.fp8_attention else {}))
                                 for s in range(n_experts)]
                     torch.cuda.synchronize()
                     alt["engine_build_s"] = round(time.time() - t0, 1)
-                    n_alt = max(1, min(args.steps, int(os.environ.get("FW_BENCH_ALT_STEPS", "5"))))
                     lat2, sid = ins["x"], 0
                     for _ in range(n_experts):
                         lat2 = one_step(sid, lat2, engines_=engines2, topo_=topo2)

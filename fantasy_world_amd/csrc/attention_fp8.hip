@@ -102,6 +102,43 @@ __global__ __launch_bounds__(256) void v_transpose_fp8_kernel(const uint16_t* __
     *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd + d) * lkp + k0 + p0) = o4;
 }
 
+// The same layout from a V that already is e4m3 (after the sequence shard's head exchange carried q | k | v as bytes): a byte gather.
+__global__ __launch_bounds__(256) void v_transpose_e4m3_kernel(const uint8_t* __restrict__ V, int64_t ldv, int64_t bsv,
+                                                               uint8_t* __restrict__ Vt, int64_t lkp, int heads, int hd, int Lk) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64][72];
+    const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tid = threadIdx.x, width = heads * hd;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;
+        const int kr = idx >> 3, cc = (idx & 7) * 8;
+        const int key = k0 + kr;
+        u32x2_t v = {0, 0};
+        if (key < Lk && c0 + cc < width) v = *(const u32x2_t*)(V + (int64_t)b * bsv + (int64_t)key * ldv + c0 + cc);
+        *(u32x2_t*)(&tile[kr][cc]) = v;
+    }
+    __syncthreads();
+    const int ch = tid >> 2, p0 = (tid & 3) * 16;
+    const int chan = c0 + ch;
+    if (chan >= width) return;
+    const int h = chan / hd, d = chan - h * hd;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pos = p0 + 4 * j + e;
+            const int hi = pos >> 5, bb = (pos >> 4) & 1, r = pos & 15;
+            const int kappa = bb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            word |= (uint32_t)tile[kappa][ch] << (8 * e);
+        }
+        w[j] = word;
+    }
+    u32x4_t o4 = {w[0], w[1], w[2], w[3]};
+    *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd + d) * lkp + k0 + p0) = o4;
+}
+
 #define FW8_MFMA(A, B, C, SB) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 0, 0, 0, 0x7f7f7f7f, 0, SB)
 
 __global__ __launch_bounds__(512, 2) void attention_fp8_kernel(Attn8Args p) {
@@ -513,10 +550,15 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_pp_kernel(Attn8Args p) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int RING_SP = 8;
 
-// max of the 16 values of an accumulator: 7 v_max3 + 1 v_max in ONE asm statement (no per-op canonicalisation).  Callers keep well over
-// the 18 wait states of a 16-pass MFMA between the MFMA that writes `v` and this read (a block's exponentials sit in between).
+// max of the 16 values of an accumulator: 7 v_max3 + 1 v_max in ONE asm statement (no per-op canonicalisation).
+// The asm statement reads MFMA results, and LLVM's hazard recogniser does not look inside inline asm (in the compiled
+// steady loop the row maximum of S1 sat EXACTLY the 18 wait states of a 16-pass XDL write behind its MFMA, 15 in the prologue).  So
+// the dependency is made visible: a v_readfirstlane of v[0] -- an ordinary VALU read of the same MFMA's destination, for which the
+// compiler inserts exactly the s_nop the hazard needs -- whose result is an (unused) input of the asm, which orders it in front.
+// Once that read may issue, the MFMA has retired all 16 registers.  tests/test_abi.py checks the compiled code for the pair.
 __device__ __forceinline__ float fw8_max16(const f32x16_t& v) {
     float r, t;
+    const int guard = __builtin_amdgcn_readfirstlane(__float_as_int(v[0]));
     asm("v_max3_f32 %0, %2, %3, %4\n\t"
         "v_max3_f32 %1, %5, %6, %7\n\t"
         "v_max3_f32 %0, %0, %8, %9\n\t"
@@ -527,7 +569,7 @@ __device__ __forceinline__ float fw8_max16(const f32x16_t& v) {
         "v_max_f32 %0, %0, %1"
         : "=&v"(r), "=&v"(t)
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
-          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "s"(guard));
     return r;
 }
 
@@ -853,6 +895,16 @@ extern "C" int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, u
         fw_set_error("fw_v_transpose_fp8: hd, ldv, bsv % 8 == 0, lkp % 64 == 0, lkp >= Lk, 16-byte aligned bases required"); return FW_E_BADARG; }
     const dim3 grid((unsigned)(lkp / 64), (unsigned)((heads * hd + 63) / 64), (unsigned)batch);
     hipLaunchKernelGGL(v_transpose_fp8_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, ldv, bsv, Vt8, lkp, heads, hd, Lk);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fw_v_transpose_e4m3(const uint8_t* V8, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads,
+                                   int hd, int Lk, void* stream) {
+    if (!V8 || !Vt8 || batch <= 0 || heads <= 0 || Lk <= 0 || hd <= 0 || (hd % 8) || (ldv % 8) || (bsv % 8) || (lkp % 64) ||
+        lkp < Lk || (((uintptr_t)V8) & 7) || (((uintptr_t)Vt8) & 15)) {
+        fw_set_error("fw_v_transpose_e4m3: hd, ldv, bsv % 8 == 0, lkp % 64 == 0, lkp >= Lk, V8 8-byte / Vt8 16-byte aligned required"); return FW_E_BADARG; }
+    const dim3 grid((unsigned)(lkp / 64), (unsigned)((heads * hd + 63) / 64), (unsigned)batch);
+    hipLaunchKernelGGL(v_transpose_e4m3_kernel, grid, dim3(256), 0, (hipStream_t)stream, V8, ldv, bsv, Vt8, lkp, heads, hd, Lk);
     return (int)hipGetLastError();
 }
 

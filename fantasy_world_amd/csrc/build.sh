@@ -5,17 +5,21 @@
 # linked library must define the host stub of every kernel it references (an undefined __device_stub__ = the library cannot load).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="${here}/../libfw_mi355x.so"
+# FW_BUILD_TAG=<tag> (A/B builds of the whole library with other flags, tools/lib_ab.py): objects csrc/<name>.<tag>.o, output
+# libfw_mi355x.<tag>.so next to the default one (never loaded unless FW_LIB_PATH points at it).  FW_MFMA_EXTRA_FLAGS: appended to the
+# flags of the MFMA files (attention*.hip, gemm*.hip), e.g. "-fno-associative-math".
+tag="${FW_BUILD_TAG:+.${FW_BUILD_TAG}}"
+out="${here}/../libfw_mi355x${tag}.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result)
+flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result ${FW_MFMA_EXTRA_FLAGS-})
 objs=()
 pids=()
 names=()
 for f in gemm.hip gemm_pp.hip attention.hip elementwise.hip heads.hip fp8.hip gemm_fp8.hip attention_fp8.hip; do
-  o="${here}/${f%.hip}.o"
+  o="${here}/${f%.hip}${tag}.o"
   # rebuild decision by CONTENT, not by mtime (round 5: this container's clock stepped backwards by minutes mid-session, so edited
   # sources were "older" than their objects and a renamed kernel silently kept its old object): hash of source + headers + this script
-  want="$(cat "${here}/$f" "${here}/fw_common.h" "${here}/gemm_common.h" "${here}/../../include/fw_mi355x.h" "${BASH_SOURCE[0]}" | sha256sum | cut -d' ' -f1) ${FW_ATTN_EXTRA_FLAGS-default}"
+  want="$(cat "${here}/$f" "${here}/fw_common.h" "${here}/gemm_common.h" "${here}/../../include/fw_mi355x.h" "${BASH_SOURCE[0]}" | sha256sum | cut -d' ' -f1) ${FW_ATTN_EXTRA_FLAGS-default} ${FW_MFMA_EXTRA_FLAGS-}"
   if [ ! -f "$o" ] || [ ! -f "$o.sha" ] || [ "$(cat "$o.sha")" != "$want" ]; then
     rm -f "$o" "$o.sha"
     echo "$want" > "$o.sha.new"
@@ -36,14 +40,14 @@ for f in gemm.hip gemm_pp.hip attention.hip elementwise.hip heads.hip fp8.hip ge
   fi
   objs+=("$o")
 done
-o="${here}/api.o"
+o="${here}/api${tag}.o"
 "$HIPCC" "${flags[@]}" -x hip -c "${here}/api.cpp" -o "$o" &
 pids+=($!); names+=("api.cpp")
 objs+=("$o")
 fail=0
 for i in "${!pids[@]}"; do
-  if ! wait "${pids[$i]}"; then echo "build.sh: compiling ${names[$i]} FAILED" >&2; fail=1; rm -f "${here}/${names[$i]%.*}.o.sha.new"
-  elif [ -f "${here}/${names[$i]%.*}.o.sha.new" ]; then mv "${here}/${names[$i]%.*}.o.sha.new" "${here}/${names[$i]%.*}.o.sha"; fi
+  if ! wait "${pids[$i]}"; then echo "build.sh: compiling ${names[$i]} FAILED" >&2; fail=1; rm -f "${here}/${names[$i]%.*}${tag}.o.sha.new"
+  elif [ -f "${here}/${names[$i]%.*}${tag}.o.sha.new" ]; then mv "${here}/${names[$i]%.*}${tag}.o.sha.new" "${here}/${names[$i]%.*}${tag}.o.sha"; fi
 done
 [ "$fail" = 0 ] || exit 1
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"

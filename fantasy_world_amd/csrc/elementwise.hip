@@ -245,19 +245,35 @@ static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t*
 // owns up to QK_MAXC chunks of 8 consecutive channels; the normalised row is parked in LDS (fp32) so the rotary
 // partner (i^1 for interleaved pairs, i +- hd/4 for the 2-D rotate-half form) can be fetched by any thread.
 // ------------------------------------------------------------------------------------------------------------
+// fw_qk_prep_fp8: the 8 results of a chunk as e4m3 bytes -- rounded to bf16 first (the value the bf16 form stores), then cast raw like
+// fw_fp8_quant_rows(raw = 1), so the fused form returns the bits of the two-pass form.
+__device__ __forceinline__ u32x2_t qk_pack_e4m3(const float* o) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = bf16_bits_to_f32(f32_to_bf16_bits(o[j]));
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    return u32x2_t{(uint32_t)lo, (uint32_t)hi};
+}
+
 constexpr int QK_MAXC = 3;     // width <= 3 * 256 * 8 = 6144
 constexpr int QK_MAXW = 6144;
 
 __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, int64_t ldx, int heads, int hd,
                                                       int norm_mode, const float* __restrict__ nw, const float* __restrict__ nb,
                                                       float eps, int rope_mode, const float* __restrict__ tab, int tab_rows, float oscale,
-                                                      const float* __restrict__ ext_ss, int norm_width) {
+                                                      const float* __restrict__ ext_ss, int norm_width,
+                                                      uint8_t* __restrict__ o8, int64_t ld8) {
     __shared__ float rowbuf[QK_MAXW];
     __shared__ float red[4];
     const int row = blockIdx.x;
     const int width = heads * hd;
     const int nch = width >> 3;
     uint16_t* xr = x + (int64_t)row * ldx;
+    uint8_t* o8r = o8 ? o8 + (int64_t)row * ld8 : nullptr;          // e4m3 output (fw_qk_prep_fp8): x stays untouched
     float v[QK_MAXC][8];
     float ss = 0.f;
 #pragma unroll
@@ -324,6 +340,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
         for (int i = 0; i < QK_MAXC; ++i) {
             const int ch = threadIdx.x + i * 256;
             if (ch < nch) {
+                if (o8r) { *(u32x2_t*)(o8r + ch * 8) = qk_pack_e4m3(v[i]); continue; }
                 u32x4_t o = {pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]),
                              pack_bf16x2(v[i][4], v[i][5]), pack_bf16x2(v[i][6], v[i][7])};
                 *(u32x4_t*)(xr + ch * 8) = o;
@@ -339,14 +356,16 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
             const int ch = threadIdx.x + i * 256;
             if (ch < nch) {
                 const int e0 = (ch * 8) % hd;      // element offset inside the head
-                uint32_t o[4];
+                float of[8];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float cs = trow[(e0 / 2 + j) * 2], sn = trow[(e0 / 2 + j) * 2 + 1];
                     const float a = v[i][2 * j], bq = v[i][2 * j + 1];
-                    o[j] = pack_bf16x2(a * cs - bq * sn, a * sn + bq * cs);
+                    of[2 * j] = a * cs - bq * sn;
+                    of[2 * j + 1] = a * sn + bq * cs;
                 }
-                u32x4_t o4 = {o[0], o[1], o[2], o[3]};
+                if (o8r) { *(u32x2_t*)(o8r + ch * 8) = qk_pack_e4m3(of); continue; }
+                u32x4_t o4 = {pack_bf16x2(of[0], of[1]), pack_bf16x2(of[2], of[3]), pack_bf16x2(of[4], of[5]), pack_bf16x2(of[6], of[7])};
                 *(u32x4_t*)(xr + ch * 8) = o4;
             }
         }
@@ -380,6 +399,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                 const float partner = rowbuf[base + j + (lo ? quarter : -quarter)];
                 o[j] = lo ? (v[i][j] * cs - partner * sn) : (v[i][j] * cs + partner * sn);
             }
+            if (o8r) { *(u32x2_t*)(o8r + base) = qk_pack_e4m3(o); continue; }
             u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
             *(u32x4_t*)(xr + base) = o4;
         }
@@ -395,7 +415,8 @@ template <int CPL, int NORM, int ROPE>
 __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int heads, int hd,
                                                            const float* __restrict__ nw, const float* __restrict__ nb, float eps,
                                                            const float* __restrict__ tab, int tab_rows, float oscale,
-                                                           const float* __restrict__ ext_ss, int norm_width) {
+                                                           const float* __restrict__ ext_ss, int norm_width,
+                                                           uint8_t* __restrict__ o8, int64_t ld8) {
     const int lane = threadIdx.x & 63;
     const int width = heads * hd;
     const int nch = width >> 3;
@@ -516,8 +537,12 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             for (int j = 0; j < 8; ++j) o[j] = v[i][j];
         }
         if (ch < nch) {
-            u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-            *(u32x4_t*)(xr + ch * 8) = o4;
+            if (o8) {       // fw_qk_prep_fp8: e4m3 bytes to the side buffer, x untouched
+                *(u32x2_t*)(o8 + (int64_t)row * ld8 + ch * 8) = qk_pack_e4m3(o);
+            } else {
+                u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                *(u32x4_t*)(xr + ch * 8) = o4;
+            }
         }
     }
     if (ROPE != FW_ROPE_NONE) {     // this row's strip reads are done before the next row's strip store
@@ -530,10 +555,10 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
 template <int CPL>
 static bool launch_qk_wave(hipStream_t st, uint16_t* x, int64_t ldx, int rows, int heads, int hd, int norm, const float* nw,
                            const float* nb, float eps, int rope, const float* tab, int tab_rows, float oscale,
-                           const float* ext_ss, int norm_width) {
+                           const float* ext_ss, int norm_width, uint8_t* o8, int64_t ld8) {
     // RMS_FULL stages 20 KiB of weights per work-group and walks the rows: 4 work-groups per CU; the other modes: one row per wave
     const dim3 grid(norm == FW_NORM_RMS_FULL ? min((rows + 3) / 4, 256 * 4) : (rows + 3) / 4), block(256);
-#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width); return true; }
+#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width, o8, ld8); return true; }
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_INTERLEAVED)
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_NONE)
     FW_QK_CASE(FW_NORM_NONE, FW_ROPE_INTERLEAVED)
@@ -712,9 +737,10 @@ extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_
 
 static int qk_prep_impl(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
                         const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
-                        const float* ext_ss, int norm_width, void* stream) {
+                        const float* ext_ss, int norm_width, void* stream, uint8_t* o8 = nullptr, int64_t ld8 = 0) {
     if (rows <= 0) return 0;
     const int width = heads * head_dim;
+    if (o8 && ((ld8 % 8) || (((uintptr_t)o8) & 7))) { fw_set_error("fw_qk_prep_fp8: out8 8-byte aligned, ld8 % 8 == 0 required"); return FW_E_BADARG; }
     if (width > QK_MAXW || (head_dim % 8) || (ldx % 8) || (((uintptr_t)x) & 15)) { fw_set_error("fw_qk_prep: width <= 6144, head_dim % 8 == 0, 16-B alignment required"); return FW_E_BADARG; }
     if (norm_mode == FW_NORM_LN_HEAD && (head_dim != 64 || !norm_w || !norm_b)) { fw_set_error("fw_qk_prep: LN_HEAD needs head_dim 64 and weight+bias"); return FW_E_BADARG; }
     if (norm_mode == FW_NORM_RMS_FULL && !norm_w) { fw_set_error("fw_qk_prep: RMS_FULL needs a weight"); return FW_E_BADARG; }
@@ -729,14 +755,14 @@ static int qk_prep_impl(uint16_t* x, int64_t ldx, int rows, int heads, int head_
             const int cpl = (width / 8 + 63) / 64;
             hipStream_t st = (hipStream_t)stream;
             bool ok = false;
-            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
-            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
-            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
+            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
+            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
+            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
             if (ok) return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL(qk_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, heads, head_dim, norm_mode,
-                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width);
+                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
     return (int)hipGetLastError();
 }
 
@@ -753,6 +779,49 @@ extern "C" int fw_qk_prep_tp(uint16_t* x, int64_t ldx, int rows, int heads, int 
     if (!row_sumsq) { fw_set_error("fw_qk_prep_tp: row_sumsq missing"); return FW_E_BADARG; }
     return qk_prep_impl(x, ldx, rows, heads, head_dim, FW_NORM_RMS_FULL, norm_w, nullptr, eps, rope_mode, rope_tab, tab_rows,
                         out_scale, row_sumsq, norm_width, stream);
+}
+
+extern "C" int fw_qk_prep_fp8(const uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
+                              const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                              const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, void* stream) {
+    if (!out8) { fw_set_error("fw_qk_prep_fp8: out8 missing"); return FW_E_BADARG; }
+    // x is only read when out8 is given (the kernels branch on it before every store)
+    return qk_prep_impl(const_cast<uint16_t*>(x), ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab,
+                        tab_rows, out_scale, row_sumsq, row_sumsq ? norm_width : 0, stream, out8, ld8);
+}
+
+// ---- per-forward modulation tables (fw_modulation_tables): one launch for all blocks of a kind --------------------------------------
+__global__ __launch_bounds__(256) void modulation_tables_kernel(const float* __restrict__ mod, const float* __restrict__ t, int t_rows,
+                                                                const float* __restrict__ ls2, float* __restrict__ table,
+                                                                float* __restrict__ g1, float* __restrict__ g0, int rows, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float* m = mod + (int64_t)b * rows * C;
+    float* o = table + (int64_t)b * rows * C;
+    float e3 = 0.f, e4 = 0.f, e5 = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float v = m[(int64_t)r * C + c] + t[(int64_t)(r % t_rows) * C + c];
+        o[(int64_t)r * C + c] = v;
+        if (r == 3) e3 = v;
+        if (r == 4) e4 = v;
+        if (r == 5) e5 = v;
+    }
+    if (ls2) {      // the tensor ops this replaces: ls2 * (1.0 + e[4]) * e[5] and ls2 * e[3] * e[5], left to right, every product rounded
+        const float l = ls2[(int64_t)b * C + c];
+        g1[(int64_t)b * C + c] = (l * (1.0f + e4)) * e5;
+        g0[(int64_t)b * C + c] = (l * e3) * e5;
+    }
+}
+
+extern "C" int fw_modulation_tables(const float* mod, const float* t, int t_rows, const float* ls2, float* table, float* g1, float* g0,
+                                    int nblk, int rows, int C, void* stream) {
+    if (!mod || !t || !table || t_rows <= 0 || rows <= 0 || C <= 0 || (ls2 && (rows != 6 || !g1 || !g0))) {
+        fw_set_error("fw_modulation_tables: mod / t / table required; ls2 needs rows == 6 and g1 / g0"); return FW_E_BADARG; }
+    if (nblk <= 0) return 0;
+    hipLaunchKernelGGL(modulation_tables_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       mod, t, t_rows, ls2, table, g1, g0, rows, C);
+    return (int)hipGetLastError();
 }
 
 // ---- head-sharded tensor parallelism helpers (fantasy_world_amd/tensor_parallel.py) ---------------------------------------------

@@ -349,6 +349,188 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp_kernel(QArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// gemm_fp8_two_slot_kernel (round 6, the default): the TWO-SLOT schedule of gemm_bf16_two_slot_kernel (csrc/gemm_pp.hip) on the fp8
+// operands.  The four-slot kernel above keeps the matrix pipe 61 % busy at 1.92 GHz (profiles/r05/clock_probe_call21_with_fp8_kernels.txt);
+// the same transformation took the bf16 GEMM from 74 % to 88 %.  The LDS image is byte-identical to the bf16 kernel's (a 128-B row is 64
+// bf16 there and 128 e4m3 here; A in two 32 KiB stages, W in THREE), and so is the slot table:
+//     slot:        2t          2t+1         2t+2         2t+3
+//     group A:   LOAD(t)     MFMA(t)      LOAD(t+1)    MFMA(t+1)          LOAD(t): W(t) fragments + A rows 0..63 of the wave tile, then
+//     group B:   MFMA(t-1)   LOAD(t)      MFMA(t)      LOAD(t+1)          this wave's 8 LDS-DMA pieces; MFMA(t): 16 MFMAs of 64 cycles in
+//                                                                         ONE burst, A rows 64..127 re-read into the consumed registers
+//   * two barriers per k-slab instead of four; no LDS-DMA instruction inside a burst (group A, LOAD(t): A0(t+1) + W rows 0..127 of
+//     slab t+2; group B, LOAD(t): A1(t+1) + W rows 128..255 of slab t+2 -- the third W stage is what lets W(t+3) be requested as soon
+//     as W(t) has been read);
+//   * pieces by buffer_load ... lds through an SGPR descriptor (rows past M / N are out of range: zeros, no clamps);
+//   * counted waits: group A vmcnt(4) at the end of its burst, group B vmcnt(8) at the end of LOAD and vmcnt(4) at the end of its burst.
+// Same k order per output element as the four-slot kernel (k-step 0 then 1 of every slab into the same accumulator): BIT-identical
+// results (tests/test_fp8_gpu.py).  FW_GEMM_KERNEL=4 selects the four-slot kernel for A/B.
+// ---------------------------------------------------------------------------------------------------------------
+#define FWQ_BLDS16(rs, voff, soff, ldsptr) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, FW_LDS_PTR(ldsptr), 16, voff, soff, 0, 0)
+constexpr int Q2_A_STAGE = QM * QK;                    // 32 KiB
+constexpr int Q2_W_BASE = 2 * Q2_A_STAGE;              // 64 KiB
+constexpr int Q2_W_STAGE = QN * QK;                    // 32 KiB
+constexpr int Q2_LDS = Q2_W_BASE + 3 * Q2_W_STAGE;     // 160 KiB
+
+__global__ __launch_bounds__(512, 2) void gemm_fp8_two_slot_kernel(QArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[Q2_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;     // XCD-contiguous tile ranges (bijective)
+    }
+    int tm, tn;
+    {
+        const int GROUP = p.tiles_n >= 20 ? 4 : 8;
+        const int per_group = GROUP * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP;
+        const int gsz = min(p.tiles_m - first_m, GROUP);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * QM, n0 = tn * QN;
+
+    const long long arem = (long long)(p.M - m0) * p.lda, wrem = (long long)(p.N - n0) * p.ldw;            // bytes
+    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0,
+                                                       (int)(unsigned)(arem > 0xffffffffLL ? 0xffffffffLL : arem), 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
+                                                       (int)(unsigned)(wrem > 0xffffffffLL ? 0xffffffffLL : wrem), 0x00020000);
+    // a piece = 8 rows x 128 B; lane -> (row pr, 16-B chunk pc); source-side swizzle chunk ^ ((row >> 1) & 7) for the even / odd piece
+    const int pr = lane >> 3, pc = lane & 7;
+    const int va[2] = {pr * (int)p.lda + ((pc ^ (pr >> 1)) << 4), pr * (int)p.lda + ((pc ^ ((pr >> 1) | 4)) << 4)};
+    const int vw[2] = {pr * (int)p.ldw + ((pc ^ (pr >> 1)) << 4), pr * (int)p.ldw + ((pc ^ ((pr >> 1) | 4)) << 4)};
+    const int astep = __builtin_amdgcn_readfirstlane((int)p.lda * 8), wstep = __builtin_amdgcn_readfirstlane((int)p.ldw * 8);
+    // this wave's 4 A pieces and 4 W pieces of every slab: tile rows (grp * 128 + 32 wn) .. + 31 of both operands
+    const int q0 = grp * 16 + 4 * wn;
+#define FWQ2_A(AS, KT, J) FWQ_BLDS16(ars, va[(J) & 1], (KT) * QK + (q0 + (J)) * astep, smem + (AS) * Q2_A_STAGE + (q0 + (J)) * 1024)
+#define FWQ2_W(WS, KT, J) FWQ_BLDS16(wrs, vw[(J) & 1], (KT) * QK + (q0 + (J)) * wstep, smem + Q2_W_BASE + (WS) * Q2_W_STAGE + (q0 + (J)) * 1024)
+    auto issue_a = [&](int as, int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) FWQ2_A(as, kt, j);
+    };
+    auto issue_w = [&](int ws, int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) FWQ2_W(ws, kt, j);
+    };
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int c0[2], c1[2];                      // byte offsets of the two 16-B chunks of k-step s inside a row
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        c0[s] = ((4 * s + 2 * hi) ^ swz) << 4;
+        c1[s] = ((4 * s + 2 * hi + 1) ^ swz) << 4;
+    }
+    const int a_row_off = (grp * 128 + fi) * 128;
+    const int b_row_off = Q2_W_BASE + (wn * 64 + fi) * 128;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    i32x8_t afr[2][2], bfr[2][2];          // [row / col block][k-step]
+
+    const int nk = p.K / QK;               // >= 4 (launcher)
+
+    // ---- prologue: A(0), W(0), A(1), W(1), W(2): every wave its own pieces, in the order the steady-state waits assume ----
+    issue_a(0, 0); issue_w(0, 0);
+    issue_a(1, 1); issue_w(1, 1);
+    issue_w(2, 2);
+    fwq_wait_vm<12>();
+    FWQ_BARRIER();
+    if (grp == 1) FWQ_BARRIER();
+
+    int kt = 0;
+    int ws = 0;                            // W stage of slab kt = kt % 3
+    auto slab = [&](auto g_tag, auto first_tag, auto n1_tag, auto n2_tag) __attribute__((always_inline)) {
+        constexpr int G = decltype(g_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value, N1 = decltype(n1_tag)::value, N2 = decltype(n2_tag)::value;   // kt == 0; kt + 1 < nk; kt + 2 < nk
+        const int as = kt & 1;
+        const char* abase = smem + as * Q2_A_STAGE;
+        const char* bbase = smem + ws * Q2_W_STAGE;
+        // ---------------- LOAD(kt): W fragments + A rows 0..63 of the wave tile, then this wave's 8 pieces
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bfr[0][s] = fwq_frag(bbase + b_row_off, c0[s], c1[s]);
+            bfr[1][s] = fwq_frag(bbase + b_row_off + 32 * 128, c0[s], c1[s]);
+            afr[0][s] = fwq_frag(abase + a_row_off, c0[s], c1[s]);
+            afr[1][s] = fwq_frag(abase + a_row_off + 32 * 128, c0[s], c1[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!FIRST && N1) {
+            issue_a(as ^ 1, kt + 1);                          // A0 / A1 of slab kt+1 -> the A stage slab kt-1 has left
+            if (N2) issue_w(ws == 0 ? 2 : ws - 1, kt + 2);    // W half of slab kt+2 -> W stage (kt+2) % 3 = (kt-1) % 3
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (G == 1 && N1) {                                   // own W-hi(kt+1) landed (group A reads it in the next slot)
+            if (FIRST) fwq_wait_vm<4>(); else if (N2) fwq_wait_vm<8>(); else fwq_wait_vm<4>();
+        }
+        FWQ_BARRIER();
+        // ---------------- MFMA(kt): 16 MFMAs in one burst; A rows 64..127 re-read into the registers the first eight have consumed
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc[0][0] = FWQ_MFMA(afr[0][s], bfr[0][s], acc[0][0]);
+            acc[0][1] = FWQ_MFMA(afr[0][s], bfr[1][s], acc[0][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            afr[0][s] = fwq_frag(abase + a_row_off + 64 * 128, c0[s], c1[s]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = FWQ_MFMA(afr[1][s], bfr[0][s], acc[1][0]);
+            acc[1][1] = FWQ_MFMA(afr[1][s], bfr[1][s], acc[1][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            afr[1][s] = fwq_frag(abase + a_row_off + 96 * 128, c0[s], c1[s]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc[2][0] = FWQ_MFMA(afr[0][s], bfr[0][s], acc[2][0]);
+            acc[2][1] = FWQ_MFMA(afr[0][s], bfr[1][s], acc[2][1]);
+            acc[3][0] = FWQ_MFMA(afr[1][s], bfr[0][s], acc[3][0]);
+            acc[3][1] = FWQ_MFMA(afr[1][s], bfr[1][s], acc[3][1]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile("" : "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+        if (N1) {                                             // own A pieces (and group A: W-lo) of slab kt+1 landed; W(kt+2) stays in flight
+            if (N2) fwq_wait_vm<4>(); else fwq_wait_vm<0>();
+        }
+        FWQ_BARRIER();
+        ++kt;
+        ws = ws == 2 ? 0 : ws + 1;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto mainloop = [&](auto g_tag) __attribute__((always_inline)) {
+        // (distinct opaque markers at both ends of an arm: without them the compiler hoists the common first LOAD above the group
+        //  branch and merges the arms' tails -- gemm_pp.hip has the finding)
+        asm volatile("; fp8 two-slot mainloop, group %0: begin" ::"n"(decltype(g_tag)::value) : "memory");
+        slab(g_tag, T{}, T{}, T{});
+        while (kt < nk - 2) slab(g_tag, F{}, T{}, T{});
+        slab(g_tag, F{}, T{}, F{});                           // kt = nk - 2
+        slab(g_tag, F{}, F{}, F{});                           // kt = nk - 1
+        asm volatile("; fp8 two-slot mainloop, group %0: end" ::"n"(decltype(g_tag)::value) : "memory");
+    };
+    if (grp == 0) { mainloop(std::integral_constant<int, 0>{}); FWQ_BARRIER(); }
+    else mainloop(std::integral_constant<int, 1>{});
+    epilogue_fp8(p, smem, acc, wave, grp, wn, fi, hi, lane, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Small / ragged shapes: 128x128x64 tile, 4 waves, register prefetch, padded LDS rows, v_mfma_f32_32x32x16_fp8_fp8 (bf16 rate;
 // these GEMMs are launch / HBM bound).  Same epilogue semantics.
 // ---------------------------------------------------------------------------------------------------------------
@@ -482,7 +664,11 @@ extern "C" int fw_gemm_fp8(const uint8_t* A, int64_t lda, const uint8_t* W, int6
         b.tiles_m = (m_big + QM - 1) / QM; b.tiles_n = (N + QN - 1) / QN;
         const int64_t nwg = (int64_t)b.tiles_m * b.tiles_n;
         if (nwg > 0x7fffffff) { fw_set_error("fw_gemm_fp8: grid too large"); return FW_E_BADARG; }
-        hipLaunchKernelGGL(gemm_fp8_pp_kernel, dim3((unsigned)nwg), dim3(512), 0, st, b);
+        // default: the two-slot kernel (32-bit byte offsets inside a tile: lda, ldw < 2^23); FW_GEMM_KERNEL=4: the four-slot kernel (A/B)
+        if (fw_get_option(FW_OPT_GEMM_KERNEL) != 4 && lda < (1 << 23) && ldw < (1 << 23))
+            hipLaunchKernelGGL(gemm_fp8_two_slot_kernel, dim3((unsigned)nwg), dim3(512), 0, st, b);
+        else
+            hipLaunchKernelGGL(gemm_fp8_pp_kernel, dim3((unsigned)nwg), dim3(512), 0, st, b);
         int rc = (int)hipGetLastError();
         if (rc || m_big == M) return rc;
     }

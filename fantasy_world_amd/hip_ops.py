@@ -29,15 +29,17 @@ SYMBOLS = [
     "fw_pixel_unshuffle", "fw_group_norm_rows", "fw_time_avg_pool", "fw_activation", "fw_softmax_rows",
     "fw_fp8_quant_rows", "fw_gemm_fp8",
     "fw_row_sumsq", "fw_qk_prep_tp", "fw_residual_add", "fw_cfg_euler_step",
+    "fw_qk_prep_fp8", "fw_v_transpose_e4m3", "fw_row_absmax", "fw_fp8_quant_rows_amax", "fw_modulation_tables",
 ]
 
 _lib = None
 
 
-def load_library(path: str = LIB_PATH):
-    """dlopen the C-ABI library and declare argument types.  Raises if it is absent (no fallback)."""
+def load_library(path: str = LIB_PATH, cache: bool = True):
+    """dlopen the C-ABI library and declare argument types.  Raises if it is absent (no fallback).
+    cache=False: a SECOND build of the library beside the process-wide one (tools/lib_ab.py: A/B of compiler flags in one process)."""
     global _lib
-    if _lib is not None:
+    if _lib is not None and cache:
         return _lib
     if not os.path.exists(path):
         raise RuntimeError(
@@ -91,6 +93,11 @@ def load_library(path: str = LIB_PATH):
         "fw_qk_prep_tp": [vp, i64, i32, i32, i32, vp, f32, i32, vp, i32, f32, vp, i32, vp],
         "fw_residual_add": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp],
         "fw_cfg_euler_step": [vp, vp, vp, vp, i64, i32, f32, f32, vp, vp],
+        "fw_qk_prep_fp8": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, f32, vp, i32, vp, i64, vp],
+        "fw_v_transpose_e4m3": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
+        "fw_row_absmax": [vp, i64, i32, i32, vp, vp],
+        "fw_fp8_quant_rows_amax": [vp, i64, vp, i64, vp, vp, i32, i32, vp],
+        "fw_modulation_tables": [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -98,9 +105,10 @@ def load_library(path: str = LIB_PATH):
         fn.argtypes = args
     lib.fw_attention_workspace_bytes.restype = i64
     lib.fw_attention_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    if lib.fw_abi_version() != 11:
+    if lib.fw_abi_version() != 12:
         raise RuntimeError("libfw_mi355x.so ABI version mismatch")
-    _lib = lib
+    if cache:
+        _lib = lib
     return lib
 
 
@@ -275,16 +283,27 @@ class HipOps:
         return out
 
     def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
-                ext_sumsq=None, norm_width=None):
+                ext_sumsq=None, norm_width=None, out8=None):
         """In place on x [rows, heads*hd] (may be a column slice of a wider buffer).  out_scale: multiplied in before the
         single bf16 rounding (the engine folds softmax_scale*log2(e) into q: see attention(q_prescaled=True)).
         ext_sumsq / norm_width (norm="rms_full" only): x is a head slice of a wider row whose sum of squares over all
-        `norm_width` channels is supplied per row (tensor parallelism: row_sumsq + all-reduce)."""
+        `norm_width` channels is supplied per row (tensor parallelism: row_sumsq + all-reduce).
+        out8 (uint8 [rows, heads*hd], row-strided ok): x is left untouched and the result goes to out8 as e4m3 bytes
+        (fw_qk_prep_fp8: the bits of cast_fp8(qk_prep(x)) without the two extra passes); returns out8."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == heads * hd
-        self._check_dev(x, norm_w, norm_b, table, ext_sumsq)
+        self._check_dev(x, norm_w, norm_b, table, ext_sumsq, out8)
         tab_rows = 0 if table is None else table.shape[0]
         if table is not None:
             assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1:] == (hd // 2, 2)
+        if out8 is not None:
+            assert out8.dtype == torch.uint8 and out8.shape == x.shape and out8.stride(1) == 1
+            if ext_sumsq is not None:
+                assert norm == "rms_full" and ext_sumsq.dtype == torch.float32 and ext_sumsq.is_contiguous() and ext_sumsq.numel() == x.shape[0]
+            _check(self.lib.fw_qk_prep_fp8(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, NORM[norm], _ptr(norm_w), _ptr(norm_b),
+                                           float(eps), ROPE[rope], _ptr(table), tab_rows, float(out_scale), _ptr(ext_sumsq),
+                                           0 if ext_sumsq is None else int(norm_width), out8.data_ptr(), out8.stride(0), self._stream()),
+                   "fw_qk_prep_fp8")
+            return out8
         if ext_sumsq is not None:
             assert norm == "rms_full" and ext_sumsq.dtype == torch.float32 and ext_sumsq.is_contiguous() and ext_sumsq.numel() == x.shape[0]
             _check(self.lib.fw_qk_prep_tp(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, _ptr(norm_w), float(eps), ROPE[rope],
@@ -569,22 +588,41 @@ class HipOps:
         wq = torch.empty(wb.shape, dtype=torch.uint8, device=self.device)
         _check(self.lib.fw_fp8_quant_rows(wb.data_ptr(), wb.stride(0), wq.data_ptr(), wq.stride(0), None, wb.shape[0], wb.shape[1],
                                           1, self._stream()), "fw_fp8_quant_rows")
-        bb = None
-        if b is not None:
-            bb = b.detach().to(device="cpu", dtype=torch.bfloat16)
-            if bias_through_fp8:
-                bb = bb.to(torch.float8_e4m3fn).to(torch.bfloat16)       # pack time, [N] values: on the host
-            bb = bb.to(device=self.device, dtype=torch.float32).contiguous()
-        return Linear(wq, bb, fp8=True)
+        return Linear(wq, None if b is None else self.fp8_bias(b, bias_through_fp8), fp8=True)
 
-    def quantize_fp8_rows(self, x):
-        """x bf16 [M, K] -> (e4m3 bytes [M, K], fp32 scale [M]): the per-row activation quantiser of fp8_linear."""
+    def fp8_bias(self, b, bias_through_fp8=True):
+        """The bias values the fp8 linear adds, as fp32 [N]: rounded to bf16 (layers.py:138) and, inside the module, through e4m3 first
+        (layers.py:158-159).  Also what a row-parallel fp8 linear adds after its all-reduce (tensor_parallel.py)."""
+        bb = b.detach().to(device="cpu", dtype=torch.bfloat16)
+        if bias_through_fp8:
+            bb = bb.to(torch.float8_e4m3fn).to(torch.bfloat16)           # pack time, [N] values: on the host
+        return bb.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def quantize_fp8_rows(self, x, amax=None):
+        """x bf16 [M, K] -> (e4m3 bytes [M, K], fp32 scale [M]): the per-row activation quantiser of fp8_linear.
+        amax (fp32 [M]): the row maximum is SUPPLIED -- x is a K-slice of a wider row (row-parallel linear under tensor parallelism:
+        row_absmax + all-reduce MAX), so every rank divides by the scale of the full row."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 8 == 0
+        self._check_dev(x, amax)
         q = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
         scale = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        if amax is not None:
+            assert amax.dtype == torch.float32 and amax.is_contiguous() and amax.numel() == x.shape[0]
+            _check(self.lib.fw_fp8_quant_rows_amax(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), amax.data_ptr(), scale.data_ptr(),
+                                                   x.shape[0], x.shape[1], self._stream()), "fw_fp8_quant_rows_amax")
+            return q, scale
         _check(self.lib.fw_fp8_quant_rows(x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), scale.data_ptr(), x.shape[0],
                                           x.shape[1], 0, self._stream()), "fw_fp8_quant_rows")
         return q, scale
+
+    def row_absmax(self, x, out=None):
+        """x bf16 [rows, w] (column slice ok) -> fp32 [rows] max |x| (exact)."""
+        assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+        self._check_dev(x, out)
+        if out is None:
+            out = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        _check(self.lib.fw_row_absmax(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), self._stream()), "fw_row_absmax")
+        return out
 
     def _linear_fp8(self, x, lin, act=None, g1=None, g0=None, res=None, out_f32=False, out=None):
         """fp8_linear(x, w, b) with the bf16 linear's fused epilogue: quantise the rows of x, e4m3 x e4m3 GEMM with fp32
@@ -615,21 +653,28 @@ class HipOps:
         """out_scale for qk_prep when q is to be cast to e4m3 for attention_fp8."""
         return self.q_scale(hd) * float(2 ** self.FP8_Q_EXP)
 
-    def cast_fp8(self, x):
-        """bf16 [rows, C] (strided rows ok) -> e4m3 bytes, raw cast (round to nearest even, no scale)."""
+    def cast_fp8(self, x, out=None):
+        """bf16 [rows, C] (strided rows ok) -> e4m3 bytes, raw cast (round to nearest even, no scale); out: uint8 view to fill."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
-        self._check_dev(x)
-        out = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        self._check_dev(x, out)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        assert out.dtype == torch.uint8 and out.shape == x.shape and out.stride(1) == 1
         _check(self.lib.fw_fp8_quant_rows(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), None, x.shape[0], x.shape[1], 1,
                                           self._stream()), "fw_fp8_quant_rows")
         return out
 
     def prepare_v_fp8(self, v, heads, hd, batch=1):
-        assert v.dtype == torch.bfloat16 and v.stride(1) == 1
+        """v [batch*Lk, heads*hd]: bf16, or e4m3 bytes already (uint8: what the head exchange delivered) -> (Vt8, Lk)."""
+        assert v.dtype in (torch.bfloat16, torch.uint8) and v.stride(1) == 1
         self._check_dev(v)
         Lk = v.shape[0] // batch
         lkp = (Lk + 63) // 64 * 64
         vt = torch.empty(batch, heads, hd, lkp, dtype=torch.uint8, device=self.device)
+        if v.dtype == torch.uint8:
+            _check(self.lib.fw_v_transpose_e4m3(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk,
+                                                self._stream()), "fw_v_transpose_e4m3")
+            return vt, Lk
         _check(self.lib.fw_v_transpose_fp8(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk,
                                            self._stream()), "fw_v_transpose_fp8")
         return vt, Lk
@@ -685,6 +730,23 @@ class HipOps:
                                           _dt(latents), float(cfg_scale), float(dsigma), _ptr(dev_params), self._stream()),
                "fw_cfg_euler_step")
         return out
+
+    def modulation_tables(self, mod, t, ls2=None):
+        """mod fp32 [nblk, rows, C] + t fp32 [t_rows, C] (row r uses t[r % t_rows]) -> table [nblk, rows, C]; with ls2 [nblk, C]
+        (rows == 6) also the fc2 epilogue's per-column scale / offset of every VGGT block: (table, g1, g0).  One launch per forward
+        for all blocks of a kind (fw_modulation_tables)."""
+        assert mod.dtype == torch.float32 and mod.dim() == 3 and mod.is_contiguous() and t.dtype == torch.float32 and t.is_contiguous()
+        self._check_dev(mod, t, ls2)
+        nblk, rows, C = mod.shape
+        t2 = t.reshape(-1, C)
+        table = torch.empty_like(mod)
+        g1 = g0 = None
+        if ls2 is not None:
+            assert ls2.dtype == torch.float32 and ls2.shape == (nblk, C) and ls2.is_contiguous() and rows == 6
+            g1, g0 = torch.empty_like(ls2), torch.empty_like(ls2)
+        _check(self.lib.fw_modulation_tables(mod.data_ptr(), t2.data_ptr(), t2.shape[0], _ptr(ls2), table.data_ptr(), _ptr(g1), _ptr(g0),
+                                             nblk, rows, C, self._stream()), "fw_modulation_tables")
+        return (table, g1, g0) if ls2 is not None else table
 
     def cast_act(self, x):
         assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1

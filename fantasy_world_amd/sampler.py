@@ -70,7 +70,10 @@ def denoise_step(engine, scheduler, step_id, latents, ctx_pos, ctx_neg, cond, cf
         # The engine fills shared state lazily on whichever stream asks first (rotary tables per grid, the all-zero verdict of the
         # Pluecker features, lazily packed heads, step-invariant cache entries): the first step on a grid therefore runs on ONE stream
         # and only later steps fork (a cold two-stream step could read a table the other stream was still writing).
-        key = tuple(latents.shape)
+        # keyed on the grid AND on the step-invariant cache's generation: after invariants.clear() (or a cache switched on later) the
+        # next step fills the cache again and must not fork
+        inv = getattr(engine, "invariants", None)
+        key = (tuple(latents.shape), getattr(inv, "generation", 0), bool(getattr(inv, "enabled", False)))
         if getattr(engine, "_cfg_streams_warm", None) != key:
             engine._cfg_streams_warm = key
             cfg_streams = False

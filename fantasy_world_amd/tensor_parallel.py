@@ -68,12 +68,12 @@ class TensorShard:
         a = sum(c[: self.rank])
         return a, a + c[self.rank], c
 
-    def all_reduce_async(self, t, kind="all_reduce") -> Pending:
-        """Sum over the group, in place on t (contiguous)."""
+    def all_reduce_async(self, t, kind="all_reduce", op=None) -> Pending:
+        """Sum (or `op`, e.g. MAX for the fp8 row maxima) over the group, in place on t (contiguous)."""
         assert t.is_contiguous()
         if self.world == 1:
             return Ready(t)
-        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=self.group, async_op=True)
         # bytes this rank sends in a bandwidth-optimal all-reduce (reduce-scatter + all-gather): 2 (n-1)/n of the message
         sent = 2 * t.numel() * t.element_size() * (self.world - 1) // self.world
         return Pending(work, lambda: t, kind, sent, t)
@@ -112,15 +112,24 @@ class TPFusionEngine(FusionEngine):
     """FusionEngine with head / column sharded weights and all-reduce (see the module docstring).  Same op set, same reference
     op order; every rank returns the full noise prediction."""
 
-    def __init__(self, cfg, get, ops, tp: TensorShard, heads_cfg=None, cache_step_invariants=False, precision="bf16"):
-        if precision != "bf16":
-            raise ValueError("the tensor-parallel partition runs the bf16 linears")
+    def __init__(self, cfg, get, ops, tp: TensorShard, heads_cfg=None, cache_step_invariants=False, precision="bf16",
+                 fp8_attention=False):
+        """precision="fp8" (round 6; BASELINE config 5 names TP = 8): the DiT blocks' linears through the reference's fp8 linear
+        (vram_management/layers.py:115-151), sharded like the bf16 ones.  Column-parallel linears (q|k|v, FFN-1, cross-attention q /
+        k|v) see the full K row: each rank quantises the replicated activation exactly as the unsharded engine does and computes its
+        output columns bit for bit.  Row-parallel linears (o, cross-attention o, FFN-2) hold a K-slice of the activation, but the
+        per-row scale_a of layers.py:126-133 is a property of the FULL row: the local row maxima are all-reduced (MAX, fp32 [rows]:
+        131 KB at L = 32 760) BEFORE quantising, so every rank divides by the same scale (fw_row_absmax, fw_fp8_quant_rows_amax);
+        the partial products (x scale_a, no bias) are all-reduced like the bf16 ones and the e4m3-rounded bias rides in the
+        epilogue after the reduction.  fp8_attention: this rank's heads through fw_attention_fp8."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision must be 'bf16' or 'fp8', got {precision!r}")
         for name, H in (("DiT", cfg.num_heads), ("VGGT", cfg.vggt_heads)):
             if not tp.divides(H):
                 raise ValueError(f"{H} {name} heads do not divide over {tp.world} tensor-parallel ranks")
         self.tp = tp
         super().__init__(cfg, get, ops, shard=None, heads_cfg=heads_cfg, cache_step_invariants=cache_step_invariants,
-                         precision=precision)
+                         precision=precision, fp8_attention=fp8_attention)
 
     # ------------------------------------------------------------------------------------------------ packing (weight slices)
     def _pack_dit(self, b, g, lin, lin_cat, prefix=None, adapter=None):
@@ -129,20 +138,25 @@ class TPFusionEngine(FusionEngine):
         hd = cfg.head_dim
         h0, h1 = tp.heads(cfg.num_heads)
         c0, c1 = h0 * hd, h1 * hd
+        f8 = self.precision == "fp8"           # the DiT block's nn.Linear modules (engine.py _pack_dit): q/k/v/o of both attentions, FFN
         pk = lambda w, bias=None: ops.pack_linear(w, bias)
+        pk8 = (lambda w, bias=None: ops.pack_linear(w, bias, fp8=True)) if f8 else pk
+        # a row-parallel linear's bias is applied AFTER the reduction (fw_residual_add): under fp8 it is the value the fp8 linear
+        # adds -- rounded to bf16 and, inside AutoWrappedLinear, through e4m3 (layers.py:138,158-159)
+        rbias = (lambda n: ops.fp8_bias(g(n))) if f8 else (lambda n: ops.to_f32(g(n)))
         rows = lambda n: (g(n + ".weight")[c0:c1], g(n + ".bias")[c0:c1])
-        cat_rows = lambda names: pk(torch.cat([rows(n)[0] for n in names], 0), torch.cat([rows(n)[1] for n in names], 0))
-        kslice = lambda n: pk(g(n + ".weight")[:, c0:c1].contiguous())                  # row-parallel: bias after the reduce
+        cat_rows = lambda names: pk8(torch.cat([rows(n)[0] for n in names], 0), torch.cat([rows(n)[1] for n in names], 0))
+        kslice = lambda n: pk8(g(n + ".weight")[:, c0:c1].contiguous())                 # row-parallel: bias after the reduce
         blk = _DitBlock()
         blk.index = b
         blk.mod = ops.to_f32(g(p + "modulation").reshape(6, cfg.dim))
         blk.qkv = cat_rows([p + "self_attn.q", p + "self_attn.k", p + "self_attn.v"])
-        blk.o, blk.o_b = kslice(p + "self_attn.o"), ops.to_f32(g(p + "self_attn.o.bias"))
+        blk.o, blk.o_b = kslice(p + "self_attn.o"), rbias(p + "self_attn.o.bias")
         blk.norm_q = ops.to_f32(g(p + "self_attn.norm_q.weight")[c0:c1])
         blk.norm_k = ops.to_f32(g(p + "self_attn.norm_k.weight")[c0:c1])
         blk.cq = cat_rows([p + "cross_attn.q"])
         blk.ckv = cat_rows([p + "cross_attn.k", p + "cross_attn.v"])
-        blk.co, blk.co_b = kslice(p + "cross_attn.o"), ops.to_f32(g(p + "cross_attn.o.bias"))
+        blk.co, blk.co_b = kslice(p + "cross_attn.o"), rbias(p + "cross_attn.o.bias")
         blk.cnorm_q = ops.to_f32(g(p + "cross_attn.norm_q.weight")[c0:c1])
         blk.cnorm_k = ops.to_f32(g(p + "cross_attn.norm_k.weight")[c0:c1])
         if cfg.has_image_input:
@@ -163,8 +177,8 @@ class TPFusionEngine(FusionEngine):
         blk.norm3_w = ops.to_f32(g(p + "norm3.weight"))
         blk.norm3_b = ops.to_f32(g(p + "norm3.bias"))
         f0, f1 = tp.units(cfg.ffn_dim)
-        blk.ffn0 = pk(g(p + "ffn.0.weight")[f0:f1], g(p + "ffn.0.bias")[f0:f1])
-        blk.ffn2, blk.ffn2_b = pk(g(p + "ffn.2.weight")[:, f0:f1].contiguous()), ops.to_f32(g(p + "ffn.2.bias"))
+        blk.ffn0 = pk8(g(p + "ffn.0.weight")[f0:f1], g(p + "ffn.0.bias")[f0:f1])
+        blk.ffn2, blk.ffn2_b = pk8(g(p + "ffn.2.weight")[:, f0:f1].contiguous()), rbias(p + "ffn.2.bias")
         return blk
 
     def _pack_vggt(self, p, g, lin):
@@ -227,8 +241,16 @@ class TPFusionEngine(FusionEngine):
         cuts = [M * i // nch // 8 * 8 for i in range(nch)] + [M]
         pend = []
         f32 = tp.reduce_dtype == torch.float32
+        rows_of = lambda a, b: x_in[a:b]
+        if lin.fp8:
+            # x_in is this rank's K-slice; the fp8 linear's per-row scale belongs to the FULL row: MAX of the local maxima over the
+            # group, then every rank quantises its slice with the same scale (bit-identical to slicing the unsharded quantised row)
+            p_amax = tp.all_reduce_async(ops.row_absmax(x_in), "all_reduce_amax", op=dist.ReduceOp.MAX)
+            yield
+            q8, scale = ops.quantize_fp8_rows(x_in, amax=p_amax.wait())
+            rows_of = lambda a, b: (q8[a:b], scale[a:b])
         for a, b in zip(cuts[:-1], cuts[1:]):
-            part = ops.linear(x_in[a:b], lin, out_f32=f32)
+            part = ops.linear(rows_of(a, b), lin, out_f32=f32)
             pend.append((a, b, tp.all_reduce_async(part, kind)))
         yield
         for a, b, p in pend:
@@ -252,7 +274,7 @@ class TPFusionEngine(FusionEngine):
         Hl = cfg.num_heads // tp.world
         W = Hl * hd
         h0 = tp.heads(cfg.num_heads)[0]
-        mod = out["mod"] = blk.mod + t_mod
+        mod = out["mod"] = self._dit_mod(blk, t_mod)
         xn = ops.layernorm(x, scale=mod[1], shift=mod[0], eps=cfg.eps)
         qkv = ops.linear(xn, blk.qkv)                                   # [L, 3 W]: this rank's heads
         q, k, v = qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:]
@@ -260,11 +282,20 @@ class TPFusionEngine(FusionEngine):
         yield
         pend.wait()
         tab = tabs["dit"]
-        ops.qk_prep(q, Hl, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
-                    out_scale=ops.q_scale(hd), ext_sumsq=sq, norm_width=D)
-        ops.qk_prep(k, Hl, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab,
-                    ext_sumsq=sk, norm_width=D)
-        o = ops.attention(q, k, v, Hl, hd, batch=1, q_prescaled=True)
+        if self.fp8_attention:       # this rank's heads on e4m3 q | k | v (fw_attention_fp8): q / k written as e4m3 by the q/k pass
+            qk8 = ops.empty(q.shape[0], 2 * W, dtype=torch.uint8)
+            ops.qk_prep(q, Hl, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
+                        out_scale=ops.q_scale_fp8(hd), ext_sumsq=sq, norm_width=D, out8=qk8[:, :W])
+            ops.qk_prep(k, Hl, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab,
+                        ext_sumsq=sk, norm_width=D, out8=qk8[:, W:])
+            vt8, Lk = ops.prepare_v_fp8(v, Hl, hd)
+            o = ops.attention_fp8(qk8[:, :W], qk8[:, W:], vt8, Hl, hd, Lk)
+        else:
+            ops.qk_prep(q, Hl, hd, norm="rms_full", norm_w=blk.norm_q, eps=cfg.eps, rope="interleaved", table=tab,
+                        out_scale=ops.q_scale(hd), ext_sumsq=sq, norm_width=D)
+            ops.qk_prep(k, Hl, hd, norm="rms_full", norm_w=blk.norm_k, eps=cfg.eps, rope="interleaved", table=tab,
+                        ext_sumsq=sk, norm_width=D)
+            o = ops.attention(q, k, v, Hl, hd, batch=1, q_prescaled=True)
         yield from self._reduce_into(x, o, blk.o, blk.o_b, g1=mod[2])
         # cross-attention: text + image keys share q (wan_video_dit.py:185-201)
         xn3 = ops.layernorm(x, w=blk.norm3_w, b=blk.norm3_b, eps=cfg.eps)
@@ -308,7 +339,7 @@ class TPFusionEngine(FusionEngine):
         hd = C // cfg.vggt_heads
         Hl = cfg.vggt_heads // tp.world
         W = Hl * hd
-        e = out["e"] = blk.mod + e0
+        e = out["e"] = self._vggt_mod(blk, e0)
         xn = ops.layernorm(tok, w=blk.norm1[0], b=blk.norm1[1], scale=e[1], shift=e[0], eps=cfg.vggt_eps)
         qkv = ops.linear(xn, blk.qkv)
         q, k, v = qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:]
@@ -323,8 +354,7 @@ class TPFusionEngine(FusionEngine):
         cfg, ops = self.cfg, self.ops
         xn = ops.layernorm(tok, w=blk.norm2[0], b=blk.norm2[1], eps=cfg.vggt_eps)
         h = ops.linear(xn, blk.fc1, act="gelu_erf")
-        g1 = blk.ls2 * (1.0 + e[4]) * e[5]
-        g0 = blk.ls2 * e[3] * e[5]
+        g1, g0 = self._vggt_gates(blk, e)
         yield from self._reduce_into(tok, h, blk.fc2, blk.fc2_b, g1=g1, g0=g0)
 
     def _tp_bicross(self, bc, x, tok, tabs):
@@ -379,6 +409,7 @@ class TPFusionEngine(FusionEngine):
         F, P, tabs, xs, t_mod, e0 = st.F, st.P, st.tabs, st.xs, st.t_mod, st.e0
         ctx_txt, ctx_img, plucker = st.ctx_txt, st.ctx_img, st.plucker
         per_block = None if collect is None else collect.get("per_block")
+        self._build_modulation(t_mod, e0)
 
         for b in range(cfg.start_index):
             blk, sd = self.dit[b], {}

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 11
+#define FW_ABI_VERSION 12
 
 /* error codes (negative; positive values are hipError_t) */
 #define FW_E_BADARG   (-1)   /* shape / alignment / enum violates the documented contract */
@@ -185,6 +185,19 @@ int fw_qk_prep_tp(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, c
                   const float* row_sumsq, int norm_width, void* stream);
 int fw_residual_add(float* x, int64_t ldx, const void* y, int64_t ldy, int y_dtype, int rows, int C,
                     const float* bias, const float* g1, const float* g0, void* stream);
+
+/*
+ * Per-forward modulation tables for ALL blocks of a kind in one launch (round 6; replaces ~330 single-work-group tensor-op launches
+ * per forward): every DiT block adds its learned [6][C] modulation to the time projection (DIT21:296-297 `self.modulation + t_mod`),
+ * every VGGT block does the same and gates its MLP with LayerScale (VB:73-81: x += (ls2 (mlp) (1 + e4) + e3) e5), the head adds the
+ * time embedding to its [2][C] table (DIT21:352-353).
+ *   table[b][r][c] = mod[b][r][c] + t[r % t_rows][c]                    b < nblk, r < rows, c < C   (fp32, contiguous)
+ *   ls2 != NULL (rows == 6):  g1[b][c] = ls2[b][c] * (1 + table[b][4][c]) * table[b][5][c]
+ *                             g0[b][c] = ls2[b][c] * table[b][3][c] * table[b][5][c]
+ * (the per-column scale / offset the fc2 GEMM's epilogue applies).  Same operation order and rounding as the tensor ops it replaces.
+ */
+int fw_modulation_tables(const float* mod, const float* t, int t_rows, const float* ls2, float* table, float* g1, float* g0,
+                         int nblk, int rows, int C, void* stream);
 
 /*
  * Sampler step on the device: out = latents + (neg + cfg_scale * (pos - neg)) * dsigma -- the CFG combine
@@ -356,6 +369,14 @@ int fw_softmax_rows(const float* s, int64_t lds, uint16_t* out, int64_t ldo, int
  * x bf16 [M][K] (ldx), q bytes [M][K] (ldq), round-to-nearest-even. */
 int fw_fp8_quant_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int M, int K, int raw, void* stream);
 
+/* Row-parallel fp8 linears under head / FFN-column tensor parallelism (round 6): a rank holds a K-slice [M][K_local] of the
+ * activation, but scale_a[m] of layers.py:126-133 is a property of the FULL row.  fw_row_absmax: out[m] = max_k |x[m][k]| of the
+ * local slice (fp32; exact, the inputs are bf16) -- all-reduced (MAX) across the ranks by the caller; fw_fp8_quant_rows_amax: the
+ * raw = 0 quantiser above with the row maximum SUPPLIED (amax[m] over the full row), so that every rank divides by the same scale. */
+int fw_row_absmax(const uint16_t* x, int64_t ldx, int rows, int width, float* out, void* stream);
+int fw_fp8_quant_rows_amax(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, const float* amax, float* scale, int M, int K,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * fp8 attention (BASELINE.json configs[4]: "CDNA4 fp8 attention + FFN"), head_dim 128 = the DiT self-attention.
  * PARITY UNPINNED: the reference has no fp8 attention (its fp8 entry is the nn.Linear swap above), so these semantics are this
@@ -368,6 +389,21 @@ int fw_fp8_quant_rows(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, f
  * lkp % 64 == 0, keys >= Lk zero; inside each 64-key tile the keys sit in the order the PV operand of fw_attention_fp8 reads them. */
 int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads, int hd, int Lk,
                        void* stream);
+
+/* The same layout from a V that is ALREADY e4m3 (one byte per element, raw cast of the bf16 V by fw_fp8_quant_rows(raw = 1)): what a
+ * rank holds after the sequence shard's head exchange has carried q | k | v as bytes (fantasy_world_amd/parallel.py).  A pure byte
+ * gather: fw_v_transpose_e4m3(cast(V)) == fw_v_transpose_fp8(V) bit for bit.  ldv / bsv in bytes (= elements), % 8 == 0. */
+int fw_v_transpose_e4m3(const uint8_t* V8, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads, int hd, int Lk,
+                        void* stream);
+
+/* fw_qk_prep / fw_qk_prep_tp writing e4m3 instead of bf16 (round 6: removes the two cast passes between the q/k pass and
+ * fw_attention_fp8): x is READ ONLY; out8[r][c] = e4m3(bf16(result[r][c])) -- the value fw_qk_prep would have stored, rounded to
+ * bf16 first, then cast raw -- so fw_qk_prep_fp8(x) == fw_fp8_quant_rows(fw_qk_prep(x), raw = 1) bit for bit.  row_sumsq /
+ * norm_width as in fw_qk_prep_tp (NULL / 0: the statistic is taken over this call's width).  ld8 in bytes, % 8 == 0. */
+int fw_qk_prep_fp8(const uint16_t* x, int64_t ldx, int rows, int heads, int head_dim,
+                   int norm_mode, const float* norm_w, const float* norm_b, float eps,
+                   int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
+                   const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, void* stream);
 
 /* O[b][q][h*128 + d] = softmax_k(Q K^T) V per (batch, head); strides of Q8 / K8 in BYTES (= elements), of O in bf16 elements. */
 int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, const uint8_t* K8, int64_t ldk, int64_t bsk,

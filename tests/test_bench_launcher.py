@@ -97,3 +97,31 @@ def test_bench_matrix_pipe_blocks_are_stored_measurements_with_provenance():
         assert "stored PMC pass" in m["source"] and "profiles/r0" in m["source"]
         assert abs(m["predicted_frac_of_2p5_pf"] - m["mfma_busy"] * m["sustained_ghz"] / 2.4) < 1e-3
     assert bench.attention_measured(80) is None          # no measurement, no number
+
+
+def test_bench_parallel_flag_selects_the_partition_without_an_environment_variable():
+    """`--parallel tp` (a driver that cannot set environment variables can still choose north_star's partition),
+    and it wins over $FW_PARALLEL; the line carries the PREDICTED step time of both partitions next to whatever gets measured."""
+    out = _run(8, extra=("--parallel", "tp"))
+    par = out["config"]["parallelism"]
+    assert "tensor-parallel x4" in par and "sequence-sharded" not in par and "sequence-sharded x4" in out["alt"]["parallelism"]
+    out = _run(4, extra=("--parallel", "sp"), env_extra={"FW_PARALLEL": "tp"})
+    assert "sequence-sharded x2" in out["config"]["parallelism"] and "tensor-parallel x2" in out["alt"]["parallelism"]
+    for blk, mode in ((out["predicted"], "sp"), (out["alt"]["predicted"], "tp")):
+        assert "PREDICTION" in blk["source"] and blk["step_ms_best"] <= blk["step_ms_worst"]
+    assert out["predicted"]["step_ms_worst"] < out["alt"]["predicted"]["step_ms_best"]        # what the default was chosen on
+
+
+def test_bench_alt_guard_scales_with_what_the_run_measured(monkeypatch):
+    """The budget of the second partition's block: 420 s at the headline's predicted step times, more when the run's own engine build
+    and step time say so (config 4 / 5: two experts at 720p), an explicit $FW_BENCH_ALT_BUDGET_S wins."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.delenv("FW_BENCH_ALT_BUDGET_S", raising=False)
+    assert bench.alt_budget_s(40.0, 500.0, 5, 1) == 420.0
+    big = bench.alt_budget_s(300.0, 3000.0, 5, 2)
+    assert big == 120.0 + 1200.0 + 12 * 7 * 3.0 and big > 420.0
+    monkeypatch.setenv("FW_BENCH_ALT_BUDGET_S", "77")
+    assert bench.alt_budget_s(300.0, 3000.0, 5, 2) == 77.0
+    assert bench.predicted_block(8, "sp", True)["step_ms_worst"] == 521 and bench.predicted_block(8, "sp", False) is None
+    assert bench.predicted_block(3, "sp", True) is None

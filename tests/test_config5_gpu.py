@@ -12,6 +12,11 @@ reproduces its own CPU golden to 1.3e-6 on this box (`ref_on_gpu/wan22/reference
     tests/test_reference_on_gpu.py::test_fp8_linear_against_the_real_scaled_mm; the real call refuses fp32 activations);
   * fp8 attention (`fp8_attention=True`) has no reference semantics (the reference defines fp8 for linears only): its distance from the
     fp8-linear checker is RECORDED, under the same physical bound as at config-1 size.
+
+Round 6: the default `-m gpu` run keeps the bf16 leg only (one fp32 reference forward at L = 111 600); the second
+reference forward -- the one with the fp8 linear in its modules, 160 s on the box -- and the two fp8 engines run with FW_CONFIG5_FP8=1
+(recorded once per round under profiles/rNN/).  The fp8-linear arithmetic stays pinned in the default run at the benchmarked DEPTH by
+tests/test_full_depth_gpu.py::test_full_depth_fp8_linears_and_fp8_attention (10 s) and at config-1 size by tests/test_fp8_gpu.py.
 """
 import os
 
@@ -46,35 +51,33 @@ def test_config5_grid_against_the_reference(parity):
         want32, _ = model.joint_forward(ins["x"], **kw)                        # the reference, fp32, PyTorch-ROCm
     torch.cuda.synchronize()
 
+    fp8_legs = os.environ.get("FW_CONFIG5_FP8", "0") == "1"
+    legs = [("bf16", {})]
+    if fp8_legs:      # fp8 attention through the SAME boundary (round 6: install(precision="fp8", fp8_attention=True))
+        legs += [("fp8_linears", dict(precision="fp8")), ("fp8_all", dict(precision="fp8", fp8_attention=True))]
     got = {}
-    for tag, opts in (("bf16", {}), ("fp8_linears", dict(precision="fp8"))):
+    for tag, opts in legs:
         eng = install(model, ops=ops, merge_cfg=False, **opts)
         got[tag], _ = model.joint_forward(ins["x"], **kw)
         torch.cuda.synchronize()
         uninstall(model)
         del eng
-    # fp8 attention is an engine option the install() boundary does not expose (parity unpinned): built directly
-    from fantasy_world_amd.engine import FusionEngine
-    params = dict(model.named_parameters())
-    eng = FusionEngine(cfg, params.__getitem__, ops, precision="fp8", fp8_attention=True)
-    ekw = {k: v for k, v in kw.items() if k not in ("timestep", "context", "use_gradient_checkpointing")}
-    got["fp8_all"], _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **ekw)
-    torch.cuda.synchronize()
-    del eng, params
     torch.cuda.empty_cache()
+    tagp = "config5/wan22_l2_f31_90x160"
+    assert all(torch.isfinite(t.float()).all() for t in got.values())
+    parity.check(f"{tagp}/bf16_engine_vs_reference_fp32", rel_l2(got["bf16"], want32), 8e-3)
+    if not fp8_legs:
+        return
 
     assert ref_harness.swap_fp8_linears(model, cfg.start_index) == 2 * len(ref_harness.FP8_SITES)
     with torch.no_grad():
         want8, _ = model.joint_forward(ins["x"], **kw)                         # the reference with the fp8 linear in those modules
     torch.cuda.synchronize()
 
-    tagp = "config5/wan22_l2_f31_90x160"
-    e = {"bf16_vs_ref_fp32": rel_l2(got["bf16"], want32), "fp8_linears_vs_ref_fp8": rel_l2(got["fp8_linears"], want8),
+    e = {"fp8_linears_vs_ref_fp8": rel_l2(got["fp8_linears"], want8),
          "fp8_linears_vs_ref_fp32": rel_l2(got["fp8_linears"], want32), "ref_fp8_vs_ref_fp32": rel_l2(want8, want32),
          "fp8_attention_vs_ref_fp8": rel_l2(got["fp8_all"], want8)}
     print(tagp, {k: f"{v:.2e}" for k, v in e.items()})
-    assert all(torch.isfinite(t.float()).all() for t in got.values())
-    parity.check(f"{tagp}/bf16_engine_vs_reference_fp32", e["bf16_vs_ref_fp32"], 8e-3)
     parity.check(f"{tagp}/fp8_linear_engine_vs_reference_with_fp8_linears", e["fp8_linears_vs_ref_fp8"], 2e-2)
     parity.note(f"{tagp}/reference_with_fp8_linears_vs_reference_fp32", e["ref_fp8_vs_ref_fp32"])
     parity.check(f"{tagp}/fp8_linear_engine_vs_reference_fp32", e["fp8_linears_vs_ref_fp32"], 1e-1)

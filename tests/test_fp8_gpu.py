@@ -215,3 +215,117 @@ def test_attention_fp8_score_spike_and_late_maximum(ops, spike_key, parity, requ
             parity.check(f"op/{request.node.name}{tag}/spiked_row", rel_l2(got[5], want[5]), 8e-2)
     finally:
         ops.set_option("attn_var", 192)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the entry points that make BASELINE config 5 launchable under both multi-GPU partitions (include/fw_mi355x.h, ABI 12).
+# Each is defined as "the bits of <an existing two-pass form>": bit-exact tests.
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("norm,rope,heads,hd,ext", [("rms_full", "interleaved", 40, 128, False), ("rms_full", "interleaved", 10, 128, True),
+                                                    ("rms_full", None, 40, 128, False), (None, "interleaved", 12, 96, False),
+                                                    ("ln_head", "half2d", 16, 64, False), (None, "half2d", 4, 128, False)])
+def test_qk_prep_fp8_returns_the_bits_of_cast_after_qk_prep(ops, norm, rope, heads, hd, ext):
+    """fw_qk_prep_fp8(x) == fw_fp8_quant_rows(fw_qk_prep(x), raw = 1) for every mode the engine uses (DiT q with the fp8 out-scale,
+    the tensor-parallel form with external statistics, both kernels: wave-per-row and -- rotate-half at head_dim 128 -- the generic one), x left untouched,
+    output written into a column slice of a wider byte buffer (what the head exchange sends)."""
+    rows, W = 777, heads * hd
+    g = torch.Generator().manual_seed(81)
+    buf = (torch.randn(rows, W + 64, generator=g) * 2).to(torch.bfloat16).cuda()
+    x = buf[:, 32:32 + W] if W % 8 == 0 else buf[:, :W]              # a column slice: strided rows
+    nw = torch.rand(W if norm == "rms_full" else hd, generator=g).cuda() + 0.5
+    nb = torch.randn(hd, generator=g).cuda() if norm == "ln_head" else None
+    tab = None
+    if rope:
+        ang = torch.randn(100, hd // 2, generator=g)
+        tab = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().cuda()
+    ss = (torch.rand(rows, generator=g) * 4 * W + 1.0).cuda() if ext else None
+    kw = dict(norm=norm, norm_w=nw if norm else None, norm_b=nb, eps=1e-6, rope=rope, table=tab, out_scale=ops.q_scale_fp8(hd),
+              ext_sumsq=ss, norm_width=4 * W if ext else None)
+    before = x.clone()
+    wide = torch.zeros(rows, 3 * W, dtype=torch.uint8, device="cuda")
+    out8 = ops.qk_prep(x, heads, hd, out8=wide[:, W:2 * W], **kw)
+    assert torch.equal(x, before) and out8.data_ptr() == wide[:, W:2 * W].data_ptr()
+    want = ops.cast_fp8(ops.qk_prep(before.clone(), heads, hd, **kw))
+    torch.cuda.synchronize()
+    assert torch.equal(out8, want)
+    assert not wide[:, :W].any() and not wide[:, 2 * W:].any()
+
+
+def test_v_transpose_of_e4m3_bytes_equals_transpose_and_cast(ops):
+    """fw_v_transpose_e4m3(cast(V)) == fw_v_transpose_fp8(V): what a rank does with the V bytes the head exchange delivered."""
+    for B, H, hd, Lk in ((2, 3, 128, 150), (1, 10, 128, 4608), (1, 1, 128, 7)):
+        v = rnd(B * Lk, 3 * H * hd, seed=91, scale=3.0).to(torch.bfloat16).cuda()[:, 2 * H * hd:]        # the v third of a q|k|v buffer
+        want, lk = ops.prepare_v_fp8(v, H, hd, batch=B)
+        got8 = torch.zeros(B * Lk, 3 * H * hd, dtype=torch.uint8, device="cuda")
+        ops.cast_fp8(v, out=got8[:, 2 * H * hd:])
+        got, lk2 = ops.prepare_v_fp8(got8[:, 2 * H * hd:], H, hd, batch=B)
+        torch.cuda.synchronize()
+        assert lk == lk2 == Lk and torch.equal(got, want)
+
+
+def test_row_parallel_fp8_quantiser_with_the_full_rows_maximum(ops, ref):
+    """fw_row_absmax + MAX + fw_fp8_quant_rows_amax on K-slices == the slices of fw_fp8_quant_rows on the full row, bit for bit (rows
+    above and below the 448 threshold), and the summed partial fp8 GEMMs reproduce the unsharded fp8 linear to fp32 round-off."""
+    M, K, N, n = 2304, 5120, 1024, 4
+    g = torch.Generator().manual_seed(93)
+    x = torch.randn(M, K, generator=g)
+    x[::3] *= 200.0                                                  # a third of the rows: scale_a > 1
+    x = x.to(torch.bfloat16).cuda()
+    q_full, s_full = ops.quantize_fp8_rows(x)
+    assert float(s_full.max()) > 1.0 and float(s_full.min()) == 1.0
+    assert torch.equal(ops.row_absmax(x).cpu(), x.float().abs().amax(dim=-1).cpu())
+    amax = torch.stack([ops.row_absmax(x[:, i * K // n:(i + 1) * K // n]) for i in range(n)]).amax(dim=0)
+    w = (torch.randn(N, K, generator=g) * 0.03)
+    lin = ops.pack_linear(w, None, fp8=True)
+    want = ops.linear(x, lin, out_f32=True)
+    acc = torch.zeros(M, N, device="cuda")
+    for i in range(n):
+        sl = slice(i * K // n, (i + 1) * K // n)
+        q, s = ops.quantize_fp8_rows(x[:, sl], amax=amax)
+        assert torch.equal(q, q_full[:, sl]) and torch.equal(s, s_full)
+        acc += ops.linear((q, s), ops.pack_linear(w[:, sl].contiguous(), None, fp8=True), out_f32=True)
+    torch.cuda.synchronize()
+    assert rel_l2(acc, want) < 1e-6
+
+
+def test_modulation_tables_are_the_tensor_ops_they_replace(ops):
+    """fw_modulation_tables == the ~330 small tensor-op launches per forward it replaces, bit for bit: mod + t for every block, and the
+    VGGT fc2 epilogue's ls2 * (1 + e4) * e5 / ls2 * e3 * e5 (left to right, every product rounded), the head's [2, C] + t."""
+    g = torch.Generator().manual_seed(95)
+    for nblk, C in ((40, 5120), (48, 1024)):
+        mod, t, ls2 = (torch.randn(*s, generator=g).cuda() for s in ((nblk, 6, C), (6, C), (nblk, C)))
+        tab, g1, g0 = ops.modulation_tables(mod, t, ls2)
+        e = mod + t
+        assert torch.equal(tab, e) and torch.equal(ops.modulation_tables(mod, t), e)
+        assert torch.equal(g1, ls2 * (1.0 + e[:, 4]) * e[:, 5]) and torch.equal(g0, ls2 * e[:, 3] * e[:, 5])
+    hm, t1 = torch.randn(1, 2, 5120, generator=g).cuda(), torch.randn(5120, generator=g).cuda()
+    assert torch.equal(ops.modulation_tables(hm, t1)[0], hm[0] + t1)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(2304, 1280, 512, "plain"), (2248, 2052, 640, "gelu"), (4193, 1152, 5120, "residual"),
+                                       (2048, 1024, 13824, "residual"), (8190, 15360, 5120, "plain"), (2560, 1024, 1024, "bf16res")])
+def test_fp8_two_slot_kernel_returns_the_bits_of_the_four_slot_kernel(ops, M, N, K, epi):
+    """gemm_fp8_two_slot_kernel (round 6, the default) against gemm_fp8_pp_kernel (FW_GEMM_KERNEL=4): same k order per output element,
+    so BIT-identical outputs -- minimal K (4 slabs: prologue + peeled tail only), ragged M and N tails (rows / columns past the edge come
+    from the buffer descriptor's range check as zeros), every epilogue family, the qkv shape of a sequence-shard rank."""
+    g = torch.Generator().manual_seed(97)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    lin = ops.pack_linear(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g) * 0.1, fp8=True)
+    xq = ops.quantize_fp8_rows(x)
+    kw = {}
+    if epi == "gelu":
+        kw = dict(act="gelu_tanh")
+    elif epi == "residual":
+        kw = dict(g1=torch.randn(N, generator=g).cuda(), res=torch.randn(M, N, generator=g).cuda(), out_f32=True)
+    elif epi == "bf16res":
+        kw = dict(g1=torch.randn(N, generator=g).cuda(), g0=torch.randn(N, generator=g).cuda(),
+                  res=torch.randn(M, N, generator=g).to(torch.bfloat16).cuda())
+    outs = {}
+    try:
+        for kern in (9, 4):
+            ops.set_option("gemm_kernel", kern)
+            outs[kern] = ops.linear(xq, lin, **kw).clone()
+            torch.cuda.synchronize()
+    finally:
+        ops.set_option("gemm_kernel", 9)
+    assert torch.isfinite(outs[9].float()).all() and torch.equal(outs[9], outs[4])

@@ -231,6 +231,56 @@ def _yardstick(model, cfg, ins, want, hip, parity):
     # the HIP path may not sit far above the rounding floor of its own storage format (10 % is the review's figure for "find the kernel";
     # the assert leaves room for the floor's own run-to-run spread of the torch kernels)
     assert hip["noise_pred"] < 1.25 * floor["noise_pred"] + 2e-4, (hip["noise_pred"], floor["noise_pred"])
+    if os.environ.get("FW_FULL_DEPTH_ABLATION", "0") == "1":
+        _ablation(model, cfg, ins, want, eng, floor["noise_pred"], parity)
+
+
+# Which bf16 STORES make the floor?  Groups of rounding sites of oracle/ref_ops.py (prefixes) at the 14B widths.
+ABLATION_SITES = {
+    "layernorm_outputs_dit": ("ln:C5120",),
+    "dit_qkv_projection_and_qk_pass": ("linear_out:N15360:K5120", "qk:hd128"),
+    "dit_self_attention_output": ("attn_o:hd128:long",),
+    "dit_ffn_hidden": ("linear_out:N13824:K5120",),
+    "dit_cross_attention_q_kv_and_outputs": ("linear_out:N5120:K5120", "linear_out:N10240:K5120", "attn_o:hd128:short"),
+    "camera_adapter_and_bridge_linears": ("linear_out:N1024:K5120", "linear_out:N2048:", "linear_out:N448:", "linear_out:N5120:K448", "cast_act"),
+    "bicross_operands_and_outputs": ("linear_out:N2304:", "qk:hd96", "attn_o:hd96"),
+    "vggt_branch_all_sites": ("ln:C1024", "linear_out:N3072:K1024", "linear_out:N4096:K1024", "qk:hd64", "attn_o:hd64"),
+    "inputs_and_context_embeddings": ("input", "linear_out:N5120:K4096", "linear_out:N1280:", "linear_out:N5120:K1280", "ln:C1280"),
+}
+
+
+def _ablation(model, cfg, ins, want, eng, floor_all, parity):
+    """Per-site decomposition of the bf16-storage floor at 40 / 24 / 24 blocks: the SAME torch-op engine (weights packed once), noise_pred
+    rel-L2 against the fp32 reference with (a) ONE group of rounding sites left in fp32 (leave-one-out: what an fp32 / split form of that
+    store could buy) and (b) ONLY that group rounded (one-in: what it costs alone); plus the attention probabilities rounded to bf16 for
+    PV the way the HIP kernels do (not part of the default floor).  Recorded under full_depth/.../ablation/*; ranked table in docs/parity.md."""
+    ops = eng.ops
+    wout = want[0].float()
+
+    def run():
+        out, _, _ = _hip_forward(model, eng, cfg, ins, False)
+        return rel_l2(out.float(), wout)
+    tag = f"full_depth/wan21/{YARDSTICK_GRID}/ablation"
+    rows = {}
+    try:
+        for name, sites in ABLATION_SITES.items():
+            ops.fp32_sites, ops.only_sites = tuple(sites), None
+            loo = run()
+            ops.fp32_sites, ops.only_sites = (), tuple(sites)
+            only = run()
+            rows[name] = {"all_but_this_in_bf16": loo, "only_this_in_bf16": only,
+                          "share_of_floor_squared": 1.0 - (loo / floor_all) ** 2}
+            parity.note(f"{tag}/{name}", rows[name])
+            print(tag, name, {k: f"{v:.3e}" for k, v in rows[name].items()}, flush=True)
+        ops.fp32_sites, ops.only_sites, ops.emulate_p = (), None, True
+        with_p = run()
+        ops.fp32_sites, ops.only_sites = (), ("attn_p",)
+        only_p = run()
+        parity.note(f"{tag}/attention_probabilities_rounded_for_pv", {"floor_with_p_rounding": with_p, "only_this_in_bf16": only_p,
+                                                                      "floor_without": floor_all})
+        print(tag, "attention P rounded to bf16 for PV", f"{with_p:.3e} (floor {floor_all:.3e}), alone {only_p:.3e}", flush=True)
+    finally:
+        ops.fp32_sites, ops.only_sites, ops.emulate_p = (), None, False
 
 
 # ---- BASELINE configs[4] ("Wan2.2 A14B fp8 MFMA path ... fp8 attention + FFN") at the benchmarked depth -------------------------
@@ -267,11 +317,15 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
     finally:
         uninstall(model)
     del eng
-    # fp8 attention is an engine option the install() boundary does not expose (parity unpinned): built directly
-    params = dict(model.named_parameters())
-    eng = FusionEngine(cfg, params.__getitem__, ops, precision="fp8", fp8_attention=True)
-    got8a = {name: _hip_forward(model, eng, cfg, ins, False) for name, ins in inputs.items()}
-    del eng, params
+    # round 6: fp8 attention through the SAME boundary -- install(model, precision="fp8", fp8_attention=True), tolerance stated in
+    # INTEGRATION.md and enforced below
+    eng = install(model, ops=ops, merge_cfg=False, precision="fp8", fp8_attention=True)
+    assert eng.fp8_attention and eng.precision == "fp8"
+    try:
+        got8a = {name: _hip_forward(model, eng, cfg, ins, False) for name, ins in inputs.items()}
+    finally:
+        uninstall(model)
+    del eng
     torch.cuda.empty_cache()
 
     assert ref_harness.swap_fp8_linears(model, cfg.start_index) == 40 * len(ref_harness.FP8_SITES)
@@ -303,3 +357,79 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
                                                rel_l2(acap["tok"][b], gcap["tok"][b]), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
         print(tag, "fp8 linears vs reference-with-fp8-linears", {k: f"{v:.2e}" for k, v in rows.items()})
         print(tag, "fp8 attention vs bf16 attention (fp8 linears in both)", {k: f"{v:.2e}" for k, v in att.items()})
+
+
+# ---- the FULL sampling schedule at the benchmarked depth (VERDICT r05 missing 3 / next 4b) ---------------------------------------------
+@pytest.mark.skipif(os.environ.get("FW_FULL_DEPTH_SCHEDULE", "0") != "1",
+                    reason="opt-in (FW_FULL_DEPTH_SCHEDULE=1): ~10 minutes of fp32 reference time on the box; recorded once per round under profiles/")
+def test_full_depth_full_schedule_latents(parity):
+    """The quantity north_star's tolerance is written on -- the LATENTS the VAE would decode -- after the reference's own 50-step loop
+    (`generate_video`, model_wan21.py:226-324: scheduler, CFG combine with scale 5, Euler updates) at 40 / 24 / 24 blocks on the grid
+    whose token count puts every GEMM / attention on the production kernels (L = 8190):
+      (1) the reference in fp32 on PyTorch-ROCm                                  -> the truth, latents after EVERY step
+      (2) the SAME call on the HIP path (install(), fp32 I/O, bf16 inside)       -> rel-L2 against (1), per step
+      (3) the reference in its OWN inference configuration (bf16 weights + autocast, inference_wan21.py:164,310) -> against (1): what the
+          reference's users actually run, as the yardstick for (2)
+      (4) the HIP path under that bf16 configuration                             -> against (3) and (1).
+    Steps via FW_FULL_DEPTH_SCHEDULE_STEPS (default 50).  Recorded per step under full_depth_schedule/*; only a physical bound is
+    enforced (a 50-step CFG loop amplifies a forward's 3e-3 by ~6.4 per step before the schedule's shrinking step sizes average it)."""
+    from fantasy_world_amd import install, uninstall, synth
+    from fantasy_world_amd.hip_ops import HipOps
+    from oracle import ref_harness
+    steps = int(os.environ.get("FW_FULL_DEPTH_SCHEDULE_STEPS", "50"))
+    cfg, model = _build("wan21")
+    f, h2, w2 = GRIDS[YARDSTICK_GRID]
+    ins = synth.make_inputs(cfg, f, h2, w2, seed=11, device=DEV, dtype=torch.float32)
+    frames = 4 * (f - 1) + 1
+    kw = dict(context_pos=ins["context"], context_neg=ins["context_neg"], clip_feature=ins["clip_feature"], y=ins["y"], height=8 * h2,
+              width=8 * w2, num_frames=frames, num_inference_steps=steps, cfg_scale=5.0, seed=0, device=DEV,
+              plucker_embedding=synth.make_plucker(frames, 8 * h2, 8 * w2).to(DEV))
+
+    def run(model, kw, autocast=False):
+        """generate_video with the latents after every scheduler.step recorded (a wrapper on the scheduler OBJECT; the loop is untouched)."""
+        import contextlib
+        import time
+        rec, sched = [], model.pipe.scheduler
+        orig = sched.step
+        sched.step = lambda *a, **k: (lambda o: (rec.append(o.detach().float().cpu()), o)[1])(orig(*a, **k))
+        t0 = time.time()
+        try:
+            with (torch.autocast("cuda", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()), ref_harness.sdpa_by_head_chunks():
+                lat, pred = model.generate_video(**kw)
+        finally:
+            del sched.step
+        _sync()
+        assert len(rec) == steps and torch.equal(rec[-1], lat.detach().float().cpu())
+        return rec, time.time() - t0
+
+    ref32, t_ref32 = run(model, kw)                                                   # (1)
+    eng = install(model, ops=HipOps(DEV))
+    try:
+        hip32, t_hip32 = run(model, kw)                                               # (2)
+    finally:
+        uninstall(model)
+    del eng
+    torch.cuda.empty_cache()
+    model.to(device=DEV, dtype=torch.bfloat16)
+    model.pipe.device, model.pipe.torch_dtype, model.device = DEV, torch.bfloat16, DEV
+    kwb = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kw.items()}
+    ref16, t_ref16 = run(model, kwb, autocast=True)                                   # (3)
+    eng = install(model, ops=HipOps(DEV))
+    try:
+        hip16, t_hip16 = run(model, kwb, autocast=True)                               # (4)
+    finally:
+        uninstall(model)
+    curves = {"hip_fp32_io_vs_reference_fp32": [rel_l2(a, b) for a, b in zip(hip32, ref32)],
+              "reference_bf16_config_vs_reference_fp32": [rel_l2(a, b) for a, b in zip(ref16, ref32)],
+              "hip_bf16_config_vs_reference_bf16_config": [rel_l2(a, b) for a, b in zip(hip16, ref16)],
+              "hip_bf16_config_vs_reference_fp32": [rel_l2(a, b) for a, b in zip(hip16, ref32)]}
+    tag = f"full_depth_schedule/wan21/{YARDSTICK_GRID}/{steps}_steps"
+    for k, v in curves.items():
+        parity.note(f"{tag}/latents_rel_l2_per_step/{k}", v)
+        print(tag, k, " ".join(f"{i + 1}:{v[i]:.2e}" for i in sorted(set([0, 1, 4, 9, 19, 29, 39, steps - 2, steps - 1])) if 0 <= i < steps), flush=True)
+    parity.note(f"{tag}/wall_seconds", {"reference_fp32": t_ref32, "hip_fp32_io": t_hip32, "reference_bf16_config": t_ref16, "hip_bf16_config": t_hip16})
+    parity.check(f"{tag}/final_latents/hip_fp32_io_vs_reference_fp32", curves["hip_fp32_io_vs_reference_fp32"][-1], 1e-1)
+    # the claim that matters for a user of the reference: on the quantity the VAE decodes, the HIP path is CLOSER to the fp32 truth than
+    # the reference's own inference configuration is
+    assert curves["hip_fp32_io_vs_reference_fp32"][-1] < curves["reference_bf16_config_vs_reference_fp32"][-1], \
+        (curves["hip_fp32_io_vs_reference_fp32"][-1], curves["reference_bf16_config_vs_reference_fp32"][-1])

@@ -49,7 +49,7 @@ def _load_weights(path):
     return torch.load(path, map_location="cpu", mmap=True, weights_only=True)
 
 
-def _worker(rank, world, port, grid, outdir, wpath, bicross_gather=False):
+def _worker(rank, world, port, grid, outdir, wpath, bicross_gather=False, opts=None, exact=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -62,7 +62,7 @@ def _worker(rank, world, port, grid, outdir, wpath, bicross_gather=False):
     cfg = _cfg()
     W = _load_weights(wpath)
     ins = synth.make_inputs(cfg, *grid, seed=3)
-    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(), shard=SequenceShard(rank, world), heads_cfg=_hc())
+    eng = FusionEngine(cfg, W.__getitem__, TorchRefOps(exact=exact), shard=SequenceShard(rank, world), heads_cfg=_hc(), **(opts or {}))
     eng.bicross_head_exchange = not bicross_gather
     from fantasy_world_amd import parallel
     stats = parallel.enable_comm_stats()
@@ -70,6 +70,8 @@ def _worker(rank, world, port, grid, outdir, wpath, bicross_gather=False):
                                   plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"],
                                   return_prediction=True)
     n_a2a = sum(1 for r in stats.records if r[0] == "all_to_all_qkv")
+    if opts:          # bytes this rank put on the wire for the q|k|v exchanges / K|V gathers (the fp8-attention engine halves the DiT share)
+        n_a2a = (n_a2a, sum(r[1] for r in stats.records if r[0] in ("all_to_all_qkv", "all_gather_rows")))
     torch.save((out, pred, n_a2a), os.path.join(outdir, f"out_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -102,6 +104,43 @@ def test_sequence_shard_matches_single_process(world, grid, bicross_gather, tmp_
         assert n_a2a == base + (0 if bicross_gather else 2), (world, bicross_gather, n_a2a)
         assert rel(got, want) < 1e-5, (r, rel(got, want))
         # last step: the frame-sharded output_list is gathered and every rank computes the same prediction dict
+        for k, v in wpred.items():
+            assert pred[k].shape == v.shape and rel(pred[k], v) < 2e-5, (r, k, rel(pred[k], v))
+
+
+@pytest.mark.parametrize("world,grid", [(2, (3, 4, 12)), (4, (5, 4, 12)), (3, (4, 4, 12))])
+def test_fp8_linears_and_fp8_attention_under_the_sequence_shard(world, grid, tmp_path, shared_weights):
+    """BASELINE config 5's arithmetic ("fp8 attention + FFN") under the sequence shard: the DiT blocks' linears
+    through the fp8 linear on L/n local rows (per-row scale: nothing to exchange) and the DiT self-attention on e4m3 q | k | v that
+    TRAVEL as bytes -- world 2 / 4 (the shard of a 4- / 8-GPU run with two CFG groups): head exchange, at world 4 in the groups (4, 6)
+    of 10 local heads, uint8 on the wire; world 3: 40 heads do not divide, the e4m3 k | v rows are all-gathered.  Every rank must reproduce the single-process fp8 engine: the same bytes reach the same
+    attention, and every other op is per row.  The CPU op set runs with exact = True (matrix products accumulated in fp64: results
+    independent of BLAS blocking) because e4m3 rounding amplifies last-bit differences of the upstream GEMMs to 6e-3 -- with it the
+    sharded ranks return the single-process values to fp32 round-off; on the HIP kernels the same comparison is BIT identity
+    (tests/test_joint_forward_gpu.py::test_hip_fp8_sequence_sharded_engine_equals_unsharded)."""
+    from fantasy_world_amd import synth
+    from fantasy_world_amd.engine import FusionEngine
+    from oracle.ref_ops import TorchRefOps
+    cfg = _cfg()
+    W, wpath = shared_weights
+    ins = synth.make_inputs(cfg, *grid, seed=3)
+    opts = dict(precision="fp8", fp8_attention=True)
+    kw = dict(clip_feature=ins["clip_feature"], y=ins["y"], plucker_fea=ins["plucker_fea"], plucker_context_lens=ins["plucker_context_lens"])
+    want, wpred = FusionEngine(cfg, W.__getitem__, TorchRefOps(exact=True), heads_cfg=_hc(), **opts).joint_forward(
+        ins["x"], ins["timestep"], ins["context"], return_prediction=True, **kw)
+    exact, _ = FusionEngine(cfg, W.__getitem__, TorchRefOps(exact=True), precision="fp8").joint_forward(
+        ins["x"], ins["timestep"], ins["context"], **kw)
+    (tmp_path / "b").mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path), wpath, False, opts, True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path / "b"), wpath, False, dict(precision="fp8"), True), nprocs=world, join=True)
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
+    assert 1e-4 < rel(want, exact) < 5e-2          # the fp8 attention really ran (and costs what e4m3 costs)
+    for r in range(world):
+        got, pred, (n_a2a, wire8) = torch.load(os.path.join(str(tmp_path), f"out_{r}.pt"))
+        _, _, (n_b, wire16) = torch.load(os.path.join(str(tmp_path / "b"), f"out_{r}.pt"))
+        assert n_a2a == n_b                        # same exchanges as the bf16-attention engine ...
+        assert wire8 < wire16                      # ... with one byte per q | k | v element of the DiT blocks on the wire
+        assert rel(got, want) < 1e-5, (r, rel(got, want))
         for k, v in wpred.items():
             assert pred[k].shape == v.shape and rel(pred[k], v) < 2e-5, (r, k, rel(pred[k], v))
 

@@ -54,6 +54,8 @@ def kernels_of(obj):
 def all_kernels():
     res = []
     for obj in sorted(glob.glob(os.path.join(ROOT, "fantasy_world_amd", "csrc", "*.o"))):
+        if os.path.basename(obj).count(".") > 1:
+            continue            # csrc/<name>.<tag>.o: an A/B build (FW_BUILD_TAG, csrc/build.sh), not the shipped library
         try:
             res += [(os.path.basename(obj),) + k for k in kernels_of(obj)]
         except subprocess.CalledProcessError:
