@@ -83,6 +83,9 @@ def parse_args(argv=None):
     ap.add_argument("--fp8-attention", action="store_true",
                     help="with --precision fp8: the DiT self-attention on e4m3 q / k / v / probabilities too (BASELINE configs[4]: "
                          "'fp8 attention + FFN'; parity unpinned -- the reference defines no fp8 attention; never the headline)")
+    ap.add_argument("--fp8-bicross", action="store_true",
+                    help="with --fp8-attention, N = 1: the bicross attention (hd 96) on e4m3 operands as well, through the hd-128 kernel on "
+                         "zero-padded heads (round-6 experiment; parity unpinned, measured under the same 2e-2; never the headline)")
     ap.add_argument("--cache-invariants", action="store_true")
     ap.add_argument("--merge-cfg", action="store_true", help="N = 1: the two CFG forwards of a step as ONE pass over 2L rows")
     ap.add_argument("--experts", type=int, default=None, help="wan22: resident experts (default 2; 1 = high-noise only)")
@@ -327,7 +330,8 @@ def main():
     t0 = time.time()
     engines = [parallel.make_engine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s), ops, topo,
                                     cache_step_invariants=args.cache_invariants, precision=args.precision,
-                                    **({"fp8_attention": True} if args.fp8_attention else {})) for s in range(n_experts)]
+                                    **({"fp8_attention": "bicross" if args.fp8_bicross else True} if args.fp8_attention else {}))
+               for s in range(n_experts)]
     torch.cuda.synchronize()
     t_build = time.time() - t0
     eng = engines[0]
@@ -369,13 +373,15 @@ def main():
         step_id += 1
     if stats is not None:
         stats.records.clear()
+    # fp8 bicross (experiment): its launches run the hd-128 fp8 kernel on 12 zero-padded heads -- told apart from the DiT self-attention by the head count
+    is_bi8 = lambda i: bool(i.get("fp8")) and i["hd"] == 128 and i["heads"] == cfg.bicross_heads and getattr(eng, "fp8_bicross", False)
     ops.start_kernel_timing({
-        "attn_hd128_self": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] >= L,
+        "attn_hd128_self": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] >= L and not is_bi8(i),
         # cross-attention: one tag per key count (512 text keys / 257 CLIP image keys), so each carries its own FLOPs
         "attn_hd128_cross_text": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] == 512,
         "attn_hd128_cross_image": lambda i: i["kind"] == "attention" and i["hd"] == 128 and i["Lk"] < 512,
-        "attn_hd96_bicross_dit_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] >= L2,
-        "attn_hd96_bicross_vggt_queries": lambda i: i["kind"] == "attention" and i["hd"] == 96 and i["Lk"] < L2,
+        "attn_hd96_bicross_dit_queries": lambda i: i["kind"] == "attention" and (i["hd"] == 96 or is_bi8(i)) and i["Lk"] >= L2,
+        "attn_hd96_bicross_vggt_queries": lambda i: i["kind"] == "attention" and (i["hd"] == 96 or is_bi8(i)) and i["Lk"] < L2,
         # frame vs global by the key count (P keys per frame vs all L2 tokens): the merged CFG pass runs both with batch > 1
         "attn_hd64_global": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["Lk"] > P,
         "attn_hd64_frame": lambda i: i["kind"] == "attention" and i["hd"] == 64 and i["Lk"] <= P,
@@ -494,7 +500,8 @@ def main():
         "metric": metric,
         "value": value, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("fp8_e4m3 linears (fp32 accumulate), " + ("fp8_e4m3 DiT self-attention (fp32 scores / softmax / accumulate; parity unpinned)"
+        "dtype": ("fp8_e4m3 linears (fp32 accumulate), " + (("fp8_e4m3 DiT self-attention" + (" and bicross attention" if getattr(eng, "fp8_bicross", False) else "")
+                                                           + " (fp32 scores / softmax / accumulate; parity unpinned)")
                                                           if fp8_attn else "bf16 attention"))
                  if args.precision == "fp8" else "bf16", "data": "synthetic",
         "config": {"workload": workload, "dit_tokens": L, "vggt_tokens": L2, "cfg_forwards_per_step": 2,

@@ -57,11 +57,22 @@ __device__ __forceinline__ int v8_pos(int kappa) {
 
 // V [b][Lk][heads*hd] bf16 -> Vt8 [b][h][d][lkp] e4m3, key axis permuted per 64-key tile (v8_pos), zero beyond Lk.
 // One work-group = 64 keys x 64 channels through LDS.
+// hd_out > hd: every head occupies hd_out rows of Vt, rows hd .. hd_out-1 zero (a head_dim-96 V laid out for the head_dim-128 kernel:
+// its PV accumulators for the padding rows stay 0)
+__device__ __forceinline__ void v8_zero_pad_rows(uint8_t* __restrict__ Vt, int64_t lkp, int b, int heads, int hd, int hd_out, int k0, int tid) {
+    const int pad = hd_out - hd;                 // rows per head to clear, 64 B each for this key tile: 4 x 16-B stores per row
+    for (int i = tid; i < heads * pad * 4; i += 256) {
+        const int h = i / (pad * 4), r = (i / 4) % pad, q = i & 3;
+        *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd_out + hd + r) * lkp + k0 + q * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+}
+
 __global__ __launch_bounds__(256) void v_transpose_fp8_kernel(const uint16_t* __restrict__ V, int64_t ldv, int64_t bsv,
-                                                              uint8_t* __restrict__ Vt, int64_t lkp, int heads, int hd, int Lk) {
+                                                              uint8_t* __restrict__ Vt, int64_t lkp, int heads, int hd, int Lk, int hd_out) {
     __shared__ uint16_t tile[64][66];
     const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int tid = threadIdx.x, width = heads * hd;
+    if (hd_out > hd && blockIdx.y == 0) v8_zero_pad_rows(Vt, lkp, b, heads, hd, hd_out, k0, tid);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = tid + it * 256;
@@ -99,15 +110,16 @@ __global__ __launch_bounds__(256) void v_transpose_fp8_kernel(const uint16_t* __
         w[j] = (uint32_t)word;
     }
     u32x4_t o4 = {w[0], w[1], w[2], w[3]};
-    *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd + d) * lkp + k0 + p0) = o4;
+    *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd_out + d) * lkp + k0 + p0) = o4;
 }
 
 // The same layout from a V that already is e4m3 (after the sequence shard's head exchange carried q | k | v as bytes): a byte gather.
 __global__ __launch_bounds__(256) void v_transpose_e4m3_kernel(const uint8_t* __restrict__ V, int64_t ldv, int64_t bsv,
-                                                               uint8_t* __restrict__ Vt, int64_t lkp, int heads, int hd, int Lk) {
+                                                               uint8_t* __restrict__ Vt, int64_t lkp, int heads, int hd, int Lk, int hd_out) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[64][72];
     const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int tid = threadIdx.x, width = heads * hd;
+    if (hd_out > hd && blockIdx.y == 0) v8_zero_pad_rows(Vt, lkp, b, heads, hd, hd_out, k0, tid);
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = tid + it * 256;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(256) void v_transpose_e4m3_kernel(const uint8_t* __
         w[j] = word;
     }
     u32x4_t o4 = {w[0], w[1], w[2], w[3]};
-    *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd + d) * lkp + k0 + p0) = o4;
+    *(u32x4_t*)(Vt + (((int64_t)b * heads + h) * hd_out + d) * lkp + k0 + p0) = o4;
 }
 
 #define FW8_MFMA(A, B, C, SB) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, C, 0, 0, 0, 0x7f7f7f7f, 0, SB)
@@ -558,7 +570,11 @@ constexpr int RING_SP = 8;
 // Once that read may issue, the MFMA has retired all 16 registers.  tests/test_abi.py checks the compiled code for the pair.
 __device__ __forceinline__ float fw8_max16(const f32x16_t& v) {
     float r, t;
+#ifdef FW8_NO_MAX_GUARD                            // A/B build only (tools/lib_ab.py): what the guard costs
+    const int guard = 0;
+#else
     const int guard = __builtin_amdgcn_readfirstlane(__float_as_int(v[0]));
+#endif
     asm("v_max3_f32 %0, %2, %3, %4\n\t"
         "v_max3_f32 %1, %5, %6, %7\n\t"
         "v_max3_f32 %0, %0, %8, %9\n\t"
@@ -757,8 +773,13 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         }
         const char* vbase = smem + sl * V8_TILE;
         float ls = 0.f;
-        // Every MFMA and the vector / LDS work that rides in its shadow form ONE scheduling region (sched_barrier fences): the
-        // interleave is the program order written here, not the scheduler's choice.
+        // Every MFMA and the vector / LDS work that rides in its shadow is fenced by sched_barrier(0) -- which pins the order INSIDE a basic
+        // block only.  `if (late) sync()` below splits the tile body into blocks, and the compiled steady loop of <0> is NOT the
+        // interleave written here (checked on the ISA): the late waves' barrier sits in front of the two S0(t+1) MFMAs, which
+        // then issue back to back; block 1's 16 exponentials, the ones-MFMA and the 4 PV MFMAs sink past the early waves' end-of-tile
+        // barrier into the loop latch (5 MFMAs back to back).  LDS ordering is intact (results identical to the in-phase arm), the
+        // measured +3.5 % of the skew stands, but its explanation is "the two halves' matrix and vector phases land half a tile apart",
+        // not a per-MFMA shadowing that the source order suggests.
 #define FW8_FENCE() __builtin_amdgcn_sched_barrier(0)
         // ---- A0: S1(t) (2 MFMAs)  ||  P of block 0; Vt d-blocks 0, 1
         FW8_FENCE();
@@ -889,22 +910,24 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
 }  // namespace
 
 extern "C" int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads,
-                                  int hd, int Lk, void* stream) {
+                                  int hd, int Lk, int hd_out, void* stream) {
+    if (hd_out <= 0) hd_out = hd;
     if (!V || !Vt8 || batch <= 0 || heads <= 0 || Lk <= 0 || hd <= 0 || (hd % 8) || (ldv % 8) || (bsv % 8) || (lkp % 64) ||
-        lkp < Lk || (((uintptr_t)V) & 15) || (((uintptr_t)Vt8) & 15)) {
-        fw_set_error("fw_v_transpose_fp8: hd, ldv, bsv % 8 == 0, lkp % 64 == 0, lkp >= Lk, 16-byte aligned bases required"); return FW_E_BADARG; }
+        lkp < Lk || hd_out < hd || (((uintptr_t)V) & 15) || (((uintptr_t)Vt8) & 15)) {
+        fw_set_error("fw_v_transpose_fp8: hd, ldv, bsv % 8 == 0, lkp % 64 == 0, lkp >= Lk, hd_out >= hd, 16-byte aligned bases required"); return FW_E_BADARG; }
     const dim3 grid((unsigned)(lkp / 64), (unsigned)((heads * hd + 63) / 64), (unsigned)batch);
-    hipLaunchKernelGGL(v_transpose_fp8_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, ldv, bsv, Vt8, lkp, heads, hd, Lk);
+    hipLaunchKernelGGL(v_transpose_fp8_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, ldv, bsv, Vt8, lkp, heads, hd, Lk, hd_out);
     return (int)hipGetLastError();
 }
 
 extern "C" int fw_v_transpose_e4m3(const uint8_t* V8, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads,
-                                   int hd, int Lk, void* stream) {
+                                   int hd, int Lk, int hd_out, void* stream) {
+    if (hd_out <= 0) hd_out = hd;
     if (!V8 || !Vt8 || batch <= 0 || heads <= 0 || Lk <= 0 || hd <= 0 || (hd % 8) || (ldv % 8) || (bsv % 8) || (lkp % 64) ||
-        lkp < Lk || (((uintptr_t)V8) & 7) || (((uintptr_t)Vt8) & 15)) {
+        lkp < Lk || hd_out < hd || (((uintptr_t)V8) & 7) || (((uintptr_t)Vt8) & 15)) {
         fw_set_error("fw_v_transpose_e4m3: hd, ldv, bsv % 8 == 0, lkp % 64 == 0, lkp >= Lk, V8 8-byte / Vt8 16-byte aligned required"); return FW_E_BADARG; }
     const dim3 grid((unsigned)(lkp / 64), (unsigned)((heads * hd + 63) / 64), (unsigned)batch);
-    hipLaunchKernelGGL(v_transpose_e4m3_kernel, grid, dim3(256), 0, (hipStream_t)stream, V8, ldv, bsv, Vt8, lkp, heads, hd, Lk);
+    hipLaunchKernelGGL(v_transpose_e4m3_kernel, grid, dim3(256), 0, (hipStream_t)stream, V8, ldv, bsv, Vt8, lkp, heads, hd, Lk, hd_out);
     return (int)hipGetLastError();
 }
 

@@ -259,6 +259,21 @@ __device__ __forceinline__ u32x2_t qk_pack_e4m3(const float* o) {
     return u32x2_t{(uint32_t)lo, (uint32_t)hi};
 }
 
+// e4m3 output with a HEAD STRIDE (hs8 >= hd bytes per head; fw_qk_prep_fp8 head_stride8): chunk at element offset e (8 | e, never straddles
+// a head) goes to head * hs8 + (e % hd); the chunk that ends a head also zero-fills the head's padding [hd, hs8) -- a head_dim-96
+// operand laid out for the head_dim-128 fp8 attention kernel (zeros contribute nothing to q k^T).
+__device__ __forceinline__ void qk_store_e4m3(uint8_t* row8, int e, int hd, int hs8, const float* o) {
+    if (hs8 == hd) { *(u32x2_t*)(row8 + e) = qk_pack_e4m3(o); return; }          // no padding: contiguous heads
+    // head index without an integer division (a long VALU sequence in a kernel that holds a whole row in registers): (e + 0.5) / hd
+    // is at least 0.5 / hd away from an integer, far beyond the fp32 error of the product for e < 6144
+    const int h = (int)(((float)e + 0.5f) * (1.0f / (float)hd)), w = e - h * hd;
+    uint8_t* dst = row8 + h * hs8 + w;
+    *(u32x2_t*)dst = qk_pack_e4m3(o);
+    if (w + 8 == hd) {
+        for (int z = hd; z < hs8; z += 8) *(u32x2_t*)(row8 + h * hs8 + z) = u32x2_t{0u, 0u};
+    }
+}
+
 constexpr int QK_MAXC = 3;     // width <= 3 * 256 * 8 = 6144
 constexpr int QK_MAXW = 6144;
 
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                                                       int norm_mode, const float* __restrict__ nw, const float* __restrict__ nb,
                                                       float eps, int rope_mode, const float* __restrict__ tab, int tab_rows, float oscale,
                                                       const float* __restrict__ ext_ss, int norm_width,
-                                                      uint8_t* __restrict__ o8, int64_t ld8) {
+                                                      uint8_t* __restrict__ o8, int64_t ld8, int hs8) {
     __shared__ float rowbuf[QK_MAXW];
     __shared__ float red[4];
     const int row = blockIdx.x;
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
         for (int i = 0; i < QK_MAXC; ++i) {
             const int ch = threadIdx.x + i * 256;
             if (ch < nch) {
-                if (o8r) { *(u32x2_t*)(o8r + ch * 8) = qk_pack_e4m3(v[i]); continue; }
+                if (o8r) { qk_store_e4m3(o8r, ch * 8, hd, hs8, v[i]); continue; }
                 u32x4_t o = {pack_bf16x2(v[i][0], v[i][1]), pack_bf16x2(v[i][2], v[i][3]),
                              pack_bf16x2(v[i][4], v[i][5]), pack_bf16x2(v[i][6], v[i][7])};
                 *(u32x4_t*)(xr + ch * 8) = o;
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                     of[2 * j] = a * cs - bq * sn;
                     of[2 * j + 1] = a * sn + bq * cs;
                 }
-                if (o8r) { *(u32x2_t*)(o8r + ch * 8) = qk_pack_e4m3(of); continue; }
+                if (o8r) { qk_store_e4m3(o8r, ch * 8, hd, hs8, of); continue; }
                 u32x4_t o4 = {pack_bf16x2(of[0], of[1]), pack_bf16x2(of[2], of[3]), pack_bf16x2(of[4], of[5]), pack_bf16x2(of[6], of[7])};
                 *(u32x4_t*)(xr + ch * 8) = o4;
             }
@@ -399,7 +414,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                 const float partner = rowbuf[base + j + (lo ? quarter : -quarter)];
                 o[j] = lo ? (v[i][j] * cs - partner * sn) : (v[i][j] * cs + partner * sn);
             }
-            if (o8r) { *(u32x2_t*)(o8r + base) = qk_pack_e4m3(o); continue; }
+            if (o8r) { qk_store_e4m3(o8r, base, hd, hs8, o); continue; }
             u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
             *(u32x4_t*)(xr + base) = o4;
         }
@@ -411,12 +426,15 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
 // Fast path of qk_prep: ONE WAVE per row, chunk (8 channels, 16 B) index = lane + 64*i, statistics and the rotate-half
 // partner exchange by wave shuffles (head_dim 64: a head is 8 consecutive lanes, the partner chunk is lane ^ 2).
 // ------------------------------------------------------------------------------------------------------------
-template <int CPL, int NORM, int ROPE>
+// OUT8: fw_qk_prep_fp8 (e4m3 to a side buffer) -- its own instantiations, so that the bf16 forms keep the register count they had
+// (the head-strided e4m3 store pushed <10, 1, 1> from 256 to 280 registers: one wave per SIMD on an HBM-bound pass)
+// (OUT8: 0 = bf16 in place, 1 = e4m3 with contiguous heads, 2 = e4m3 with a head stride and zero padding)
+template <int CPL, int NORM, int ROPE, int OUT8>
 __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict__ x, int64_t ldx, int rows, int heads, int hd,
                                                            const float* __restrict__ nw, const float* __restrict__ nb, float eps,
                                                            const float* __restrict__ tab, int tab_rows, float oscale,
                                                            const float* __restrict__ ext_ss, int norm_width,
-                                                           uint8_t* __restrict__ o8, int64_t ld8) {
+                                                           uint8_t* __restrict__ o8, int64_t ld8, int hs8) {
     const int lane = threadIdx.x & 63;
     const int width = heads * hd;
     const int nch = width >> 3;
@@ -537,8 +555,10 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             for (int j = 0; j < 8; ++j) o[j] = v[i][j];
         }
         if (ch < nch) {
-            if (o8) {       // fw_qk_prep_fp8: e4m3 bytes to the side buffer, x untouched
+            if (OUT8 == 1) {        // fw_qk_prep_fp8: e4m3 bytes to the side buffer, x untouched
                 *(u32x2_t*)(o8 + (int64_t)row * ld8 + ch * 8) = qk_pack_e4m3(o);
+            } else if (OUT8 == 2) {
+                qk_store_e4m3(o8 + (int64_t)row * ld8, ch * 8, hd, hs8, o);
             } else {
                 u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
                 *(u32x4_t*)(xr + ch * 8) = o4;
@@ -555,10 +575,14 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
 template <int CPL>
 static bool launch_qk_wave(hipStream_t st, uint16_t* x, int64_t ldx, int rows, int heads, int hd, int norm, const float* nw,
                            const float* nb, float eps, int rope, const float* tab, int tab_rows, float oscale,
-                           const float* ext_ss, int norm_width, uint8_t* o8, int64_t ld8) {
+                           const float* ext_ss, int norm_width, uint8_t* o8, int64_t ld8, int hs8) {
     // RMS_FULL stages 20 KiB of weights per work-group and walks the rows: 4 work-groups per CU; the other modes: one row per wave
     const dim3 grid(norm == FW_NORM_RMS_FULL ? min((rows + 3) / 4, 256 * 4) : (rows + 3) / 4), block(256);
-#define FW_QK_CASE(N, R) if (norm == N && rope == R) { hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width, o8, ld8); return true; }
+#define FW_QK_CASE(N, R) if (norm == N && rope == R) { \
+        if (o8 && hs8 != hd) hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R, 2>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width, o8, ld8, hs8); \
+        else if (o8) hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R, 1>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width, o8, ld8, hs8); \
+        else hipLaunchKernelGGL((qk_prep_wave_kernel<CPL, N, R, 0>), grid, block, 0, st, x, ldx, rows, heads, hd, nw, nb, eps, tab, tab_rows, oscale, ext_ss, norm_width, o8, ld8, hs8); \
+        return true; }
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_INTERLEAVED)
     FW_QK_CASE(FW_NORM_RMS_FULL, FW_ROPE_NONE)
     FW_QK_CASE(FW_NORM_NONE, FW_ROPE_INTERLEAVED)
@@ -737,10 +761,12 @@ extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_
 
 static int qk_prep_impl(uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
                         const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
-                        const float* ext_ss, int norm_width, void* stream, uint8_t* o8 = nullptr, int64_t ld8 = 0) {
+                        const float* ext_ss, int norm_width, void* stream, uint8_t* o8 = nullptr, int64_t ld8 = 0, int hs8 = 0) {
     if (rows <= 0) return 0;
     const int width = heads * head_dim;
-    if (o8 && ((ld8 % 8) || (((uintptr_t)o8) & 7))) { fw_set_error("fw_qk_prep_fp8: out8 8-byte aligned, ld8 % 8 == 0 required"); return FW_E_BADARG; }
+    if (hs8 <= 0) hs8 = head_dim;
+    if (o8 && ((ld8 % 8) || (((uintptr_t)o8) & 7) || hs8 < head_dim || (hs8 % 8))) {
+        fw_set_error("fw_qk_prep_fp8: out8 8-byte aligned, ld8 % 8 == 0, head_stride8 >= head_dim and % 8 == 0 required"); return FW_E_BADARG; }
     if (width > QK_MAXW || (head_dim % 8) || (ldx % 8) || (((uintptr_t)x) & 15)) { fw_set_error("fw_qk_prep: width <= 6144, head_dim % 8 == 0, 16-B alignment required"); return FW_E_BADARG; }
     if (norm_mode == FW_NORM_LN_HEAD && (head_dim != 64 || !norm_w || !norm_b)) { fw_set_error("fw_qk_prep: LN_HEAD needs head_dim 64 and weight+bias"); return FW_E_BADARG; }
     if (norm_mode == FW_NORM_RMS_FULL && !norm_w) { fw_set_error("fw_qk_prep: RMS_FULL needs a weight"); return FW_E_BADARG; }
@@ -755,14 +781,14 @@ static int qk_prep_impl(uint16_t* x, int64_t ldx, int rows, int heads, int head_
             const int cpl = (width / 8 + 63) / 64;
             hipStream_t st = (hipStream_t)stream;
             bool ok = false;
-            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
-            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
-            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
+            if (cpl <= 2) ok = launch_qk_wave<2>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8, hs8);
+            else if (cpl <= 3) ok = launch_qk_wave<3>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8, hs8);
+            else if (cpl <= 10) ok = launch_qk_wave<10>(st, x, ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8, hs8);
             if (ok) return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL(qk_prep_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ldx, heads, head_dim, norm_mode,
-                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8);
+                       norm_w, norm_b, eps, rope_mode, rope_tab, tab_rows, out_scale, ext_ss, norm_width, o8, ld8, hs8);
     return (int)hipGetLastError();
 }
 
@@ -783,11 +809,11 @@ extern "C" int fw_qk_prep_tp(uint16_t* x, int64_t ldx, int rows, int heads, int 
 
 extern "C" int fw_qk_prep_fp8(const uint16_t* x, int64_t ldx, int rows, int heads, int head_dim, int norm_mode, const float* norm_w,
                               const float* norm_b, float eps, int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
-                              const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, void* stream) {
+                              const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, int head_stride8, void* stream) {
     if (!out8) { fw_set_error("fw_qk_prep_fp8: out8 missing"); return FW_E_BADARG; }
     // x is only read when out8 is given (the kernels branch on it before every store)
     return qk_prep_impl(const_cast<uint16_t*>(x), ldx, rows, heads, head_dim, norm_mode, norm_w, norm_b, eps, rope_mode, rope_tab,
-                        tab_rows, out_scale, row_sumsq, row_sumsq ? norm_width : 0, stream, out8, ld8);
+                        tab_rows, out_scale, row_sumsq, row_sumsq ? norm_width : 0, stream, out8, ld8, head_stride8);
 }
 
 // ---- per-forward modulation tables (fw_modulation_tables): one launch for all blocks of a kind --------------------------------------

@@ -730,6 +730,193 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4b_kernel(GemmArgs p) {
     epilogue_w4(p, smem, acc, wave, wm, wn, fi, hi, lane, m0, n0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_bf16_w4c_kernel (round 6 experiment, FW_GEMM_KERNEL=7): the four-wave kernel above with the global -> LDS path the vendor
+// library's kernel for these shapes uses -- buffer_load_dwordx4 into VGPRs, ds_write_b128 into the stage -- instead of LDS-DMA.
+// Why: gemm_bf16_w4b_kernel's finding is that a global_load_lds BLOCKS the issuing wave until the texture-address path accepts it
+// (+1000 cycles per slab with one wave per SIMD and nobody else to issue MFMAs meanwhile); an ordinary VMEM load returns its issue slot
+// at once and the ds_write costs an LDS issue like a fragment read.  One wave per SIMD has the registers for it: 256 accumulators in the
+// accumulation half, 64 staging registers (this wave's 16 pieces of one slab), 64 fragment registers.
+//   body(T) (after the barrier of slab T: slab T+1 in stage (T+1)&1, everyone done reading stage T&1; stg[] = slab T+2, requested a slab ago):
+//     P3: MFMA k-step 3 of slab T   | read frags(T+1, k0) | every 3rd MFMA: ds_write stg[i] -> stage T&1, then stg[i] <- load slab T+3
+//     P0: MFMA k-step 0 of slab T+1 | read frags(T+1, k1) |   (16 pieces over the 48 MFMA slots of P3, P0, P1)
+//     P1: MFMA k-step 1             | read frags(T+1, k2) |
+//     P2: MFMA k-step 2             | read frags(T+1, k3) ; lgkmcnt(0) (own writes done), s_barrier -- NO vmcnt wait: the loads of slab
+//                                                           T+3 stay in flight across the barrier and are waited for piece by piece
+// Same LDS image, fragment reads, k order and epilogue as w4b: bit-identical results.  Rows past M / N: buffer descriptor range (zeros).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4c_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int GM = p.group_m;
+        const int per_group = GM * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GM;
+        const int gsz = min(p.tiles_m - first_m, GM);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    const long long arem = (long long)(p.M - m0) * p.lda * 2, wrem = (long long)(p.N - n0) * p.ldw * 2;
+    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0,
+                                                       (int)(unsigned)(arem > 0xffffffffLL ? 0xffffffffLL : arem), 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
+                                                       (int)(unsigned)(wrem > 0xffffffffLL ? 0xffffffffLL : wrem), 0x00020000);
+    // a piece = 8 rows x 128 B: lane -> row pr, chunk pc; the swizzle chunk ^ ((row >> 1) & 7) sits on the SOURCE address (even / odd
+    // piece), so the LDS destination is lane-linear like the DMA's: piece base + lane * 16
+    const int pr = lane >> 3, pc = lane & 7;
+    const int va[2] = {pr * (int)p.lda * 2 + ((pc ^ (pr >> 1)) << 4), pr * (int)p.lda * 2 + ((pc ^ ((pr >> 1) | 4)) << 4)};
+    const int vw[2] = {pr * (int)p.ldw * 2 + ((pc ^ (pr >> 1)) << 4), pr * (int)p.ldw * 2 + ((pc ^ ((pr >> 1) | 4)) << 4)};
+    const int astep = __builtin_amdgcn_readfirstlane((int)p.lda * 16), wstep = __builtin_amdgcn_readfirstlane((int)p.ldw * 16);
+    const int pq = wave * 8;                   // this wave's pieces 8w .. 8w+7 of both operands (tile rows 64w .. 64w+63)
+#define FW_4C_LDA(KT, I) __builtin_amdgcn_raw_buffer_load_b128(ars, va[(I) & 1], (KT) * (BK * 2) + (pq + (I)) * astep, 0)
+#define FW_4C_LDW(KT, I) __builtin_amdgcn_raw_buffer_load_b128(wrs, vw[(I) & 1], (KT) * (BK * 2) + (pq + (I)) * wstep, 0)
+    char* const wr_base = smem + pq * 1024 + lane * 16;      // + stage * STAGE2 (+ TM * BK * 2 for W) + piece * 1024
+
+    // prologue slabs 0 and 1 by LDS-DMA (as in w4b: nothing to overlap with yet)
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[8], woff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+    }
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int a_addr[4], b_addr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = ((2 * ks + hi) ^ swz) << 4;
+        a_addr[ks] = (wm * 128 + fi) * 128 + c;
+        b_addr[ks] = TM * BK * 2 + (wn * 128 + fi) * 128 + c;
+    }
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t fa[2][4], fb[2][4];
+    u32x4_t stg[16];                           // staging: A pieces 0..7, W pieces 0..7 of ONE slab
+
+    const int nk = p.K / BK;                   // >= 4 (launcher)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { FW_GLDS16(abase + aoff[i], smem + (wave * 8 + i) * 1024); FW_GLDS16(wbase + woff[i], smem + TM * BK * 2 + (wave * 8 + i) * 1024); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { FW_GLDS16(abase + BK * 2 + aoff[i], smem + STAGE2 + (wave * 8 + i) * 1024); FW_GLDS16(wbase + BK * 2 + woff[i], smem + STAGE2 + TM * BK * 2 + (wave * 8 + i) * 1024); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { stg[i] = FW_4C_LDA(2, i); stg[8 + i] = FW_4C_LDW(2, i); }      // slab 2 into the staging registers
+    // (the BUILTIN, not inline asm: the compiler's wait-count pass reads it, learns that the LDS-DMA of slab 0 is done and keeps exact
+    //  per-register counts for the staged loads -- with the asm form it assumed LDS-DMA still pending at the loop head and put a
+    //  vmcnt(0) in front of the first fragment read of every slab, which waits for the loads requested one k-step earlier)
+    __builtin_amdgcn_s_waitcnt(0x8F70);        // vmcnt(32): slab 0 landed (slab 1's DMA and slab 2's loads stay in flight)
+    FW_BARRIER();
+
+    // One k-step: 16 MFMAs on fragment set CUR; after MFMAs 0..7 the 8 fragment reads of k-step `rks` of stage `rst` into the other
+    // set; PIECES: at every third MFMA slot g = GB + j one piece i = g / 3 -- ds_write of stg[i] into stage `dst`, then (LOADS) the
+    // request of the same piece of slab `dk` into stg[i].  Nothing may be reordered across the fences.
+    auto kstep = [&](auto cur_tag, auto read_tag, auto dma_tag, auto loads_tag, int rst, int rks, int dst, int dk) __attribute__((always_inline)) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr bool READ = decltype(read_tag)::value;
+        constexpr int GB = decltype(dma_tag)::value;            // -1: no pieces in this k-step; else first of its 16 global MFMA slots (0 / 16 / 32)
+        constexpr bool LOADS = decltype(loads_tag)::value;
+        const char* rbase = smem + rst * STAGE2;
+        char* wbase_l = wr_base + dst * STAGE2;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[CUR][rb], fb[CUR][nb], acc[rb][nb], 0, 0, 0);
+                const int j = rb * 4 + nb;                      // 0..15
+                if (READ && j < 8) {
+                    FW_NOMOVE();
+                    if (j & 1) fb[CUR ^ 1][j >> 1] = *(const bf16x8_t*)(rbase + b_addr[rks] + (j >> 1) * 4096);
+                    else fa[CUR ^ 1][j >> 1] = *(const bf16x8_t*)(rbase + a_addr[rks] + (j >> 1) * 4096);
+                    FW_NOMOVE();
+                }
+                if (GB >= 0 && (GB + j) % 3 == 0) {
+                    const int i = (GB + j) / 3;                 // 0..15: A pieces 0..7, then W pieces 0..7
+                    FW_NOMOVE();
+                    *(u32x4_t*)(wbase_l + (i < 8 ? i * 1024 : TM * BK * 2 + (i - 8) * 1024)) = stg[i];
+                    if (LOADS) stg[i] = i < 8 ? FW_4C_LDA(dk, i) : FW_4C_LDW(dk, i - 8);
+                    FW_NOMOVE();
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using DN = std::integral_constant<int, -1>;
+    using D0 = std::integral_constant<int, 0>;
+    using D16 = std::integral_constant<int, 16>;
+    using D32 = std::integral_constant<int, 32>;
+
+    // prologue: slab 0 k-steps 0..2, then the barrier that opens slab 1
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        fa[0][rb] = *(const bf16x8_t*)(smem + a_addr[0] + rb * 4096);
+        fb[0][rb] = *(const bf16x8_t*)(smem + b_addr[0] + rb * 4096);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    kstep(S0{}, T{}, DN{}, F{}, 0, 1, 0, 0);
+    kstep(S1{}, T{}, DN{}, F{}, 0, 2, 0, 0);
+    kstep(S0{}, T{}, DN{}, F{}, 0, 3, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x4F70);        // vmcnt(16): slab 1 landed (the 16 loads of slab 2 stay in flight)
+    FW_BARRIER();
+
+    int Tk = 0;
+    auto body = [&](auto has2_tag, auto has3_tag) __attribute__((always_inline)) {
+        constexpr bool HAS2 = decltype(has2_tag)::value, HAS3 = decltype(has3_tag)::value;
+        const int sn = (Tk + 1) & 1, so = Tk & 1;
+        if (HAS2) {
+            kstep(S1{}, T{}, D0{}, has3_tag, sn, 0, so, Tk + 3);        // P3: MFMA slots  0..15
+            kstep(S0{}, T{}, D16{}, has3_tag, sn, 1, so, Tk + 3);       // P0: MFMA slots 16..31
+            kstep(S1{}, T{}, D32{}, has3_tag, sn, 2, so, Tk + 3);       // P1: MFMA slots 32..47
+        } else {
+            kstep(S1{}, T{}, DN{}, F{}, sn, 0, so, 0);
+            kstep(S0{}, T{}, DN{}, F{}, sn, 1, so, 0);
+            kstep(S1{}, T{}, DN{}, F{}, sn, 2, so, 0);
+        }
+        kstep(S0{}, T{}, DN{}, F{}, sn, 3, so, 0);                      // P2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // own ds_writes (slab T+2) and fragment reads done; loads stay in flight
+        FW_BARRIER();
+        ++Tk;
+    };
+    while (Tk < nk - 3) body(T{}, T{});
+    body(T{}, F{});                                                     // Tk = nk-3: writes slab nk-1, nothing left to request
+    body(F{}, F{});                                                     // Tk = nk-2: slab nk-1 k-steps 0..2
+    kstep(S1{}, F{}, DN{}, F{}, 0, 0, 0, 0);                            // k-step 3 of the last slab
+    __builtin_amdgcn_s_setprio(0);
+    FW_BARRIER();
+    epilogue_w4(p, smem, acc, wave, wm, wn, fi, hi, lane, m0, n0);
+}
+
 // fp32 GEMV for the M=1 time-embedding MLPs: one wave per output feature.
 __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, float* __restrict__ out,
@@ -817,6 +1004,8 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         // 6 ... = the two-slot ping-pong kernels of round 4 (gemm_pp.hip)
         if (kern == 5) {
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        } else if (kern == 7 && p.lda < (1 << 21) && p.ldw < (1 << 21)) {      // round-6 experiment: four waves, VGPR-staged loads
+            hipLaunchKernelGGL(gemm_bf16_w4c_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (kern >= 6 && fw_launch_gemm_pp(p, kern, fw_get_option(FW_OPT_GEMM_VAR), st)) {
         } else if (fw_get_option(FW_OPT_GEMM_VAR) & 2) {
             hipLaunchKernelGGL((gemm_bf16_four_slot_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, st, p);      // TIMING build

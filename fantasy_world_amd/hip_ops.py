@@ -72,7 +72,7 @@ def load_library(path: str = LIB_PATH, cache: bool = True):
         "fw_im2col3x3": [vp, i64, vp, i64, i32, i32, i32, i32, vp],
         "fw_im2col": [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
         "fw_conv_gemm_bf16": [vp, i64] + [i32] * 14 + [vp, i64, vp, i64, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp],
-        "fw_v_transpose_fp8": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
+        "fw_v_transpose_fp8": [vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp],
         "fw_attention_fp8": [vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp],
         "fw_softmax_rows": [vp, i64, vp, i64, i32, i32, i32, f32, vp],
         "fw_fp8_quant_rows": [vp, i64, vp, i64, vp, i32, i32, i32, vp],
@@ -93,8 +93,8 @@ def load_library(path: str = LIB_PATH, cache: bool = True):
         "fw_qk_prep_tp": [vp, i64, i32, i32, i32, vp, f32, i32, vp, i32, f32, vp, i32, vp],
         "fw_residual_add": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp],
         "fw_cfg_euler_step": [vp, vp, vp, vp, i64, i32, f32, f32, vp, vp],
-        "fw_qk_prep_fp8": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, f32, vp, i32, vp, i64, vp],
-        "fw_v_transpose_e4m3": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
+        "fw_qk_prep_fp8": [vp, i64, i32, i32, i32, i32, vp, vp, f32, i32, vp, i32, f32, vp, i32, vp, i64, i32, vp],
+        "fw_v_transpose_e4m3": [vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp],
         "fw_row_absmax": [vp, i64, i32, i32, vp, vp],
         "fw_fp8_quant_rows_amax": [vp, i64, vp, i64, vp, vp, i32, i32, vp],
         "fw_modulation_tables": [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp],
@@ -283,25 +283,27 @@ class HipOps:
         return out
 
     def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
-                ext_sumsq=None, norm_width=None, out8=None):
+                ext_sumsq=None, norm_width=None, out8=None, head_stride8=None):
         """In place on x [rows, heads*hd] (may be a column slice of a wider buffer).  out_scale: multiplied in before the
         single bf16 rounding (the engine folds softmax_scale*log2(e) into q: see attention(q_prescaled=True)).
         ext_sumsq / norm_width (norm="rms_full" only): x is a head slice of a wider row whose sum of squares over all
         `norm_width` channels is supplied per row (tensor parallelism: row_sumsq + all-reduce).
         out8 (uint8 [rows, heads*hd], row-strided ok): x is left untouched and the result goes to out8 as e4m3 bytes
-        (fw_qk_prep_fp8: the bits of cast_fp8(qk_prep(x)) without the two extra passes); returns out8."""
+        (fw_qk_prep_fp8: the bits of cast_fp8(qk_prep(x)) without the two extra passes); returns out8.
+        head_stride8 > hd: out8 is [rows, heads*head_stride8], every head zero-padded to head_stride8 bytes."""
         assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == heads * hd
         self._check_dev(x, norm_w, norm_b, table, ext_sumsq, out8)
         tab_rows = 0 if table is None else table.shape[0]
         if table is not None:
             assert table.dtype == torch.float32 and table.is_contiguous() and table.shape[1:] == (hd // 2, 2)
         if out8 is not None:
-            assert out8.dtype == torch.uint8 and out8.shape == x.shape and out8.stride(1) == 1
+            hs8 = int(head_stride8 or hd)
+            assert out8.dtype == torch.uint8 and out8.shape == (x.shape[0], heads * hs8) and out8.stride(1) == 1
             if ext_sumsq is not None:
                 assert norm == "rms_full" and ext_sumsq.dtype == torch.float32 and ext_sumsq.is_contiguous() and ext_sumsq.numel() == x.shape[0]
             _check(self.lib.fw_qk_prep_fp8(x.data_ptr(), x.stride(0), x.shape[0], heads, hd, NORM[norm], _ptr(norm_w), _ptr(norm_b),
                                            float(eps), ROPE[rope], _ptr(table), tab_rows, float(out_scale), _ptr(ext_sumsq),
-                                           0 if ext_sumsq is None else int(norm_width), out8.data_ptr(), out8.stride(0), self._stream()),
+                                           0 if ext_sumsq is None else int(norm_width), out8.data_ptr(), out8.stride(0), hs8, self._stream()),
                    "fw_qk_prep_fp8")
             return out8
         if ext_sumsq is not None:
@@ -664,18 +666,20 @@ class HipOps:
                                           self._stream()), "fw_fp8_quant_rows")
         return out
 
-    def prepare_v_fp8(self, v, heads, hd, batch=1):
-        """v [batch*Lk, heads*hd]: bf16, or e4m3 bytes already (uint8: what the head exchange delivered) -> (Vt8, Lk)."""
+    def prepare_v_fp8(self, v, heads, hd, batch=1, hd_out=None):
+        """v [batch*Lk, heads*hd]: bf16, or e4m3 bytes already (uint8: what the head exchange delivered) -> (Vt8, Lk).
+        hd_out > hd: Vt8 has hd_out rows per head, the extra rows zero (a head_dim-96 V for the head_dim-128 kernel)."""
         assert v.dtype in (torch.bfloat16, torch.uint8) and v.stride(1) == 1
         self._check_dev(v)
         Lk = v.shape[0] // batch
         lkp = (Lk + 63) // 64 * 64
-        vt = torch.empty(batch, heads, hd, lkp, dtype=torch.uint8, device=self.device)
+        ho = int(hd_out or hd)
+        vt = torch.empty(batch, heads, ho, lkp, dtype=torch.uint8, device=self.device)
         if v.dtype == torch.uint8:
-            _check(self.lib.fw_v_transpose_e4m3(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk,
+            _check(self.lib.fw_v_transpose_e4m3(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk, ho,
                                                 self._stream()), "fw_v_transpose_e4m3")
             return vt, Lk
-        _check(self.lib.fw_v_transpose_fp8(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk,
+        _check(self.lib.fw_v_transpose_fp8(v.data_ptr(), v.stride(0), Lk * v.stride(0), vt.data_ptr(), lkp, batch, heads, hd, Lk, ho,
                                            self._stream()), "fw_v_transpose_fp8")
         return vt, Lk
 

@@ -385,25 +385,29 @@ int fw_fp8_quant_rows_amax(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t l
  * softmax in fp32, P = e4m3(2^(s - m + 7)), O accumulated in fp32, written as bf16.  Opt-in (FusionEngine(fp8_attention=True)).
  * ------------------------------------------------------------------------------------------------------------- */
 
-/* V [batch][Lk][heads*hd] bf16 (row stride ldv, batch stride bsv, elements) -> Vt8 [batch][heads][hd][lkp] e4m3 bytes,
- * lkp % 64 == 0, keys >= Lk zero; inside each 64-key tile the keys sit in the order the PV operand of fw_attention_fp8 reads them. */
+/* V [batch][Lk][heads*hd] bf16 (row stride ldv, batch stride bsv, elements) -> Vt8 [batch][heads][hd_out][lkp] e4m3 bytes,
+ * lkp % 64 == 0, keys >= Lk zero; inside each 64-key tile the keys sit in the order the PV operand of fw_attention_fp8 reads them.
+ * hd_out (0 = hd): rows per head of Vt8; rows hd .. hd_out-1 are written as zeros -- a head_dim-96 operand (the bicross attention)
+ * laid out for the head_dim-128 kernel. */
 int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads, int hd, int Lk,
-                       void* stream);
+                       int hd_out, void* stream);
 
 /* The same layout from a V that is ALREADY e4m3 (one byte per element, raw cast of the bf16 V by fw_fp8_quant_rows(raw = 1)): what a
  * rank holds after the sequence shard's head exchange has carried q | k | v as bytes (fantasy_world_amd/parallel.py).  A pure byte
  * gather: fw_v_transpose_e4m3(cast(V)) == fw_v_transpose_fp8(V) bit for bit.  ldv / bsv in bytes (= elements), % 8 == 0. */
 int fw_v_transpose_e4m3(const uint8_t* V8, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads, int hd, int Lk,
-                        void* stream);
+                        int hd_out, void* stream);
 
 /* fw_qk_prep / fw_qk_prep_tp writing e4m3 instead of bf16 (round 6: removes the two cast passes between the q/k pass and
  * fw_attention_fp8): x is READ ONLY; out8[r][c] = e4m3(bf16(result[r][c])) -- the value fw_qk_prep would have stored, rounded to
  * bf16 first, then cast raw -- so fw_qk_prep_fp8(x) == fw_fp8_quant_rows(fw_qk_prep(x), raw = 1) bit for bit.  row_sumsq /
- * norm_width as in fw_qk_prep_tp (NULL / 0: the statistic is taken over this call's width).  ld8 in bytes, % 8 == 0. */
+ * norm_width as in fw_qk_prep_tp (NULL / 0: the statistic is taken over this call's width).  ld8 in bytes, % 8 == 0.
+ * head_stride8 (0 = head_dim): bytes per head in out8; > head_dim pads every head with zeros ([head_dim, head_stride8)) -- the
+ * head_dim-96 q / k of the bicross attention laid out for the head_dim-128 kernel (zeros add nothing to q k^T). */
 int fw_qk_prep_fp8(const uint16_t* x, int64_t ldx, int rows, int heads, int head_dim,
                    int norm_mode, const float* norm_w, const float* norm_b, float eps,
                    int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
-                   const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, void* stream);
+                   const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, int head_stride8, void* stream);
 
 /* O[b][q][h*128 + d] = softmax_k(Q K^T) V per (batch, head); strides of Q8 / K8 in BYTES (= elements), of O in bf16 elements. */
 int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, const uint8_t* K8, int64_t ldk, int64_t bsk,

@@ -131,10 +131,15 @@ class TorchRefOps:
         return self._r(y, f"ln:C{x.shape[-1]}")
 
     def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
-                ext_sumsq=None, norm_width=None, out8=None):
+                ext_sumsq=None, norm_width=None, out8=None, head_stride8=None):
         if out8 is not None:          # fw_qk_prep_fp8 by its definition: cast_fp8(qk_prep(copy of x)), x untouched
             tmp = self.qk_prep(x.clone(), heads, hd, norm, norm_w, norm_b, eps, rope, table, out_scale, ext_sumsq, norm_width)
-            return self.cast_fp8(tmp, out=out8)
+            hs = int(head_stride8 or hd)
+            if hs == hd:
+                return self.cast_fp8(tmp, out=out8)
+            out8.zero_()              # every head zero-padded to head_stride8 bytes
+            out8.view(x.shape[0], heads, hs)[:, :, :hd] = self.cast_fp8(tmp).view(x.shape[0], heads, hd)
+            return out8
         rows = x.shape[0]
         v = x.to(torch.float32)
         if norm == "rms_full" and ext_sumsq is not None:         # head slice of a wider row: statistic supplied (fw_qk_prep_tp)
@@ -421,8 +426,13 @@ class TorchRefOps:
             return out
         return q
 
-    def prepare_v_fp8(self, v, heads, hd, batch=1):
+    def prepare_v_fp8(self, v, heads, hd, batch=1, hd_out=None):
         v8 = v if v.dtype == torch.uint8 else self.cast_fp8(v)
+        ho = int(hd_out or hd)
+        if ho != hd:                  # rows hd .. hd_out-1 of every head: zeros
+            pad = torch.zeros(v8.shape[0], heads, ho, dtype=torch.uint8, device=v8.device)
+            pad[:, :, :hd] = v8.reshape(v8.shape[0], heads, hd)
+            v8 = pad.reshape(v8.shape[0], heads * ho)
         return v8, v.shape[0] // batch
 
     def attention_fp8(self, q8, k8, vt8, heads, hd, Lk, batch=1, out=None):

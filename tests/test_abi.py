@@ -67,7 +67,7 @@ def test_argument_validation_needs_no_gpu():
     bad(cg(p, 64, 64, 2, 4, 4, 1, 3, 3, 1, 1, 1, 1, 1, 1, 2, p, 576, p, 64, 1, 64, None, 0, None, None, None, 0, 0, None), "bad geometry")
     bad(cg(p, 64, 64, 1, 5000, 4, 1, 3, 3, 1, 1, 1, 1, 1, 0, 1, p, 576, p, 64, 1, 64, None, 0, None, None, None, 0, 0, None), "chunk the volume")
     bad(cg(p, 64, 64, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 1, 0, 1, p, 512, p, 64, 1, 64, None, 0, None, None, None, 0, 0, None), "ldw < taps")
-    bad(lib.fw_v_transpose_fp8(p, 128, 128 * 4, p, 100, 1, 1, 128, 4, None), "fw_v_transpose_fp8")            # lkp % 64 != 0
+    bad(lib.fw_v_transpose_fp8(p, 128, 128 * 4, p, 100, 1, 1, 128, 4, 0, None), "fw_v_transpose_fp8")         # lkp % 64 != 0
     bad(lib.fw_attention_fp8(p, 128, 0, p, 128, 0, p, 64, p, 128, 0, 1, 1, 96, 4, 4, 3, None), "head_dim must be 128")
     bad(lib.fw_attention_fp8(p, 120, 0, p, 128, 0, p, 64, p, 128, 0, 1, 1, 128, 4, 4, 3, None), "alignment contract")
     bad(lib.fw_resize_bilinear(p, 60, p, 60, 1, 2, 2, 4, 4, 60, None), "fw_resize_bilinear")
@@ -105,7 +105,8 @@ def test_hot_kernels_do_not_spill():
     must_be_clean = ["attention_sp_kernel<128, 65>", "attention_sp_kernel<128, 1>", "attention_sp_kernel<64, 1>", "attention_sp_kernel<96, 1>",
                      "attention_pp3_kernel<96, 0>", "gemm_bf16_two_slot_kernel<0>", "gemm_bf16_four_slot_kernel<0, false>", "gemm_bf16_four_slot_kernel<0, true>",
                      "gemm_fp8_pp_kernel", "gemm_fp8_two_slot_kernel", "layernorm_lds_kernel<20, false, true>", "layernorm_lds_kernel<20, true, false>",
-                     "layernorm_lds_kernel<4, true, true>", "qk_prep_wave_kernel<10, 1, 1>"]
+                     "layernorm_lds_kernel<4, true, true>", "qk_prep_wave_kernel<10, 1, 1, 0>", "qk_prep_wave_kernel<10, 1, 1, 1>",
+                     "qk_prep_wave_kernel<3, 0, 1, 2>"]
     for k in must_be_clean:
         assert k in table, (k, sorted(table)[:5])
         assert table[k][3] == 0, f"{k}: {table[k][3]} bytes of scratch (vgpr {table[k][0]})"

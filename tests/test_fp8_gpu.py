@@ -329,3 +329,32 @@ def test_fp8_two_slot_kernel_returns_the_bits_of_the_four_slot_kernel(ops, M, N,
     finally:
         ops.set_option("gemm_kernel", 9)
     assert torch.isfinite(outs[9].float()).all() and torch.equal(outs[9], outs[4])
+
+
+def test_head_padded_e4m3_operands_for_the_hd128_kernel(ops):
+    """head_stride8 / hd_out (round 6): a head_dim-96 q / k / v laid out head by head in 128 bytes / rows with zero padding, so the
+    hd-128 fp8 attention kernel runs the bicross attention unchanged.  The real bytes are the unpadded form's, the padding is zero, and
+    the attention over the padded operands equals the fp32 softmax over the 96 real channels within the fp8 kernel's tolerance."""
+    H, hd, Lq, Lk = 12, 96, 700, 830
+    g = torch.Generator().manual_seed(99)
+    q, k, v = (torch.randn(n, H * hd, generator=g).to(torch.bfloat16).cuda() for n in (Lq, Lk, Lk))
+    ang = torch.randn(1000, hd // 2, generator=g)
+    tab = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().cuda()
+    kw = dict(rope="interleaved", table=tab)
+    flat = ops.qk_prep(q, H, hd, out_scale=ops.q_scale_fp8(hd), out8=torch.empty(Lq, H * hd, dtype=torch.uint8, device="cuda"), **kw)
+    q8 = ops.qk_prep(q, H, hd, out_scale=ops.q_scale_fp8(hd), out8=torch.full((Lq, H * 128), 77, dtype=torch.uint8, device="cuda"),
+                     head_stride8=128, **kw)
+    k8 = ops.qk_prep(k, H, hd, out8=torch.full((Lk, H * 128), 77, dtype=torch.uint8, device="cuda"), head_stride8=128, **kw)
+    assert torch.equal(q8.view(Lq, H, 128)[:, :, :hd], flat.view(Lq, H, hd)) and not q8.view(Lq, H, 128)[:, :, hd:].any()
+    vt, lk = ops.prepare_v_fp8(v, H, hd)
+    vtp, _ = ops.prepare_v_fp8(v, H, hd, hd_out=128)
+    assert vtp.shape == (1, H, 128, vt.shape[-1]) and torch.equal(vtp[:, :, :hd], vt) and not vtp[:, :, hd:].any()
+    v8 = ops.cast_fp8(v)
+    assert torch.equal(ops.prepare_v_fp8(v8, H, hd, hd_out=128)[0], vtp)
+    o = ops.attention_fp8(q8, k8, vtp, H, 128, lk)
+    torch.cuda.synchronize()
+    assert not o.view(Lq, H, 128)[:, :, hd:].any()                       # padded output columns: exactly zero
+    qr = ops.qk_prep(q.clone(), H, hd, **kw).float()
+    kr = ops.qk_prep(k.clone(), H, hd, **kw).float()
+    want = _attn_ref(qr, kr, v.float(), 1, H, hd)
+    assert rel_l2(o.view(Lq, H, 128)[:, :, :hd].reshape(Lq, H * hd).float(), want) < 8e-2

@@ -327,6 +327,28 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
         uninstall(model)
     del eng
     torch.cuda.empty_cache()
+    # round 6 experiment (opt-in): the bicross attention on e4m3 operands as well -- against the engine with fp8 DiT attention only,
+    # under the same stated 2e-2: noise_pred and both streams (the VGGT stream after block 39 is what the geometry heads read)
+    if os.environ.get("FW_FULL_DEPTH_FP8_BICROSS", "0") == "1":
+        eng = install(model, ops=ops, merge_cfg=False, precision="fp8", fp8_attention="bicross")
+        assert eng.fp8_bicross
+        try:
+            got8b = {name: _hip_forward(model, eng, cfg, ins, False) for name, ins in inputs.items()}
+        finally:
+            uninstall(model)
+        del eng
+        torch.cuda.empty_cache()
+        for name in inputs:
+            tag = f"full_depth_fp8/wan22/{name}/fp8_bicross_vs_bf16_bicross_fp8_dit_attention_in_both"
+            (aout, _, acap), (bout, _, bcap) = got8a[name], got8b[name]
+            row = {"noise_pred": parity.check(f"{tag}/noise_pred", rel_l2(bout.float(), aout.float()), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)}
+            for b, what in WATCH.items():
+                row[f"x@{b}"] = parity.check(f"{tag}/x_stream_after_block_{b}_{what}", rel_l2(bcap["x"][b], acap["x"][b]),
+                                             FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
+                if b >= cfg.start_index:
+                    row[f"tok@{b}"] = parity.check(f"{tag}/vggt_stream_after_block_{b}_{what}", rel_l2(bcap["tok"][b], acap["tok"][b]),
+                                                   FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
+            print(tag, {k: f"{v:.2e}" for k, v in row.items()}, flush=True)
 
     assert ref_harness.swap_fp8_linears(model, cfg.start_index) == 40 * len(ref_harness.FP8_SITES)
     for name, ins in inputs.items():

@@ -104,14 +104,15 @@ def test_gemm_big_tile_kernels_agree(ops, ref, M, N, K, parity):
     xd = bf(x).cuda()
     try:
         outs = {}
-        for kern in (4, 5, 9):
+        for kern in (4, 5, 7, 9):
             ops.set_option("gemm_kernel", kern)
             outs[kern] = ops.linear(xd, lin, out_f32=True)
         torch.cuda.synchronize()
     finally:
         ops.set_option("gemm_kernel", 9)
     parity.check(f"op/gemm_big_f32out/{M}x{N}x{K}", rel_l2(outs[9], want), 1e-3)
-    for kern in (4, 5):                # 9 = the default (two-slot ping-pong, round 4); 4 = four-slot ping-pong; 5 = four waves
+    for kern in (4, 5, 7):             # 9 = the default (two-slot ping-pong, round 4); 4 = four-slot ping-pong; 5 = four waves (LDS-DMA);
+                                       # 7 = four waves with VGPR-staged loads (round 6)
         assert torch.equal(outs[kern], outs[9]), kern
 
 

@@ -132,14 +132,17 @@ def test_fp8_linears_and_fp8_attention_under_the_sequence_shard(world, grid, tmp
         ins["x"], ins["timestep"], ins["context"], **kw)
     (tmp_path / "b").mkdir()
     mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path), wpath, False, opts, True), nprocs=world, join=True)
-    mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path / "b"), wpath, False, dict(precision="fp8"), True), nprocs=world, join=True)
+    wire_twin = world == 4          # the bf16-attention twin (what its exchanges put on the wire) once, at the 8-GPU layout's shard
+    if wire_twin:
+        mp.spawn(_worker, args=(world, _free_port(), grid, str(tmp_path / "b"), wpath, False, dict(precision="fp8"), True), nprocs=world, join=True)
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()
     assert 1e-4 < rel(want, exact) < 5e-2          # the fp8 attention really ran (and costs what e4m3 costs)
     for r in range(world):
         got, pred, (n_a2a, wire8) = torch.load(os.path.join(str(tmp_path), f"out_{r}.pt"))
-        _, _, (n_b, wire16) = torch.load(os.path.join(str(tmp_path / "b"), f"out_{r}.pt"))
-        assert n_a2a == n_b                        # same exchanges as the bf16-attention engine ...
-        assert wire8 < wire16                      # ... with one byte per q | k | v element of the DiT blocks on the wire
+        if wire_twin:
+            _, _, (n_b, wire16) = torch.load(os.path.join(str(tmp_path / "b"), f"out_{r}.pt"))
+            assert n_a2a == n_b                    # same exchanges as the bf16-attention engine ...
+            assert wire8 < wire16                  # ... with one byte per q | k | v element of the DiT blocks on the wire
         assert rel(got, want) < 1e-5, (r, rel(got, want))
         for k, v in wpred.items():
             assert pred[k].shape == v.shape and rel(pred[k], v) < 2e-5, (r, k, rel(pred[k], v))
