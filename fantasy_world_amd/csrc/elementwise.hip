@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __r
                                                                  uint16_t* __restrict__ y, int64_t ldy, int rows, int C,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                 float eps) {
+                                                                 float eps, uint16_t* __restrict__ ylo) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -173,6 +173,12 @@ __global__ __launch_bounds__(256) void layernorm_mod_wave_kernel(const void* __r
                                     shift != nullptr, shift ? *(const f32x4_t*)(shift + c0) : zero);
         u32x2_t out = {pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3])};
         *(u32x2_t*)(yr + c0) = out;
+        if (ylo) {      // fw_layernorm_mod_split: the part of t the bf16 rounding dropped, as a second bf16 (hi + lo carries ~16 bits)
+            const float r0 = t[0] - __uint_as_float(out[0] << 16), r1 = t[1] - __uint_as_float(out[0] & 0xffff0000u);
+            const float r2 = t[2] - __uint_as_float(out[1] << 16), r3 = t[3] - __uint_as_float(out[1] & 0xffff0000u);
+            u32x2_t lo = {pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
+            *(u32x2_t*)(ylo + (int64_t)row * ldy + c0) = lo;
+        }
     }
 }
 
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(256) void layernorm_lds_kernel(const float* __restr
 
 template <bool XF32>
 static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t* y, int64_t ldy, int rows, int C,
-                           const float* w, const float* b, const float* scale, const float* shift, float eps) {
-    if (XF32 && rows >= 4096 && (C == 5120 || C == 1024)) {
+                           const float* w, const float* b, const float* scale, const float* shift, float eps, uint16_t* ylo = nullptr) {
+    if (XF32 && rows >= 4096 && (C == 5120 || C == 1024) && !ylo) {
         // parameters staged in LDS (20 KiB per vector at C = 5120: 4 work-groups per CU; 4 KiB at C = 1024: 8 per CU), rows walked
         const bool aff = w && b, mod = scale && shift;
         const bool pure = (aff || (!w && !b)) && (mod || (!scale && !shift));       // no half-specified pairs on this path
@@ -232,7 +238,7 @@ static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t*
 #undef FW_LN_LDS
     }
     const dim3 grid((rows + 3) / 4), block(256);
-#define FW_LN_CASE(V) case V: hipLaunchKernelGGL((layernorm_mod_wave_kernel<XF32, V>), grid, block, 0, st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps); return true;
+#define FW_LN_CASE(V) case V: hipLaunchKernelGGL((layernorm_mod_wave_kernel<XF32, V>), grid, block, 0, st, x, ldx, y, ldy, rows, C, w, b, scale, shift, eps, ylo); return true;
     switch (C / 256) {
         FW_LN_CASE(4) FW_LN_CASE(5) FW_LN_CASE(8) FW_LN_CASE(20)
         default: return false;
@@ -756,6 +762,20 @@ extern "C" int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_
     }
     if (x_dtype == FW_DT_F32) hipLaunchKernelGGL(layernorm_mod_kernel<true>, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, C, w, b, scale, shift, eps);
     else if (x_dtype == FW_DT_BF16) hipLaunchKernelGGL(layernorm_mod_kernel<false>, dim3(rows), dim3(256), 0, st, x, ldx, y, ldy, C, w, b, scale, shift, eps);
+    return (int)hipGetLastError();
+}
+
+// LayerNorm whose output keeps what the bf16 rounding drops: y = y_hi + y_lo, both bf16 (round 6; the per-site ablation of the bf16
+// floor found ONE store worth a third of it -- the LayerNorm in front of the output head, whose rounding reaches noise_pred with no
+// residual stream to average it: docs/parity.md).  The consumer runs its (tiny) GEMM on both parts.  fp32 input, C % 256 == 0.
+extern "C" int fw_layernorm_mod_split(const float* x, int64_t ldx, uint16_t* y_hi, uint16_t* y_lo, int64_t ldy, int rows, int C,
+                                      const float* w, const float* b, const float* scale, const float* shift, float eps, void* stream) {
+    if (rows <= 0) return 0;
+    const bool pal = ((((uintptr_t)w) | ((uintptr_t)b) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0;
+    if (!x || !y_hi || !y_lo || C <= 0 || (C % 256) || (ldx % 4) || (ldy % 4) || (((uintptr_t)x) & 15) || ((((uintptr_t)y_hi) | ((uintptr_t)y_lo)) & 7) || !pal) {
+        fw_set_error("fw_layernorm_mod_split: fp32 x, C % 256 == 0 (1024 / 1280 / 2048 / 5120), 16-B aligned rows and parameter vectors required"); return FW_E_BADARG; }
+    if (!launch_ln_wave<true>((hipStream_t)stream, x, ldx, y_hi, ldy, rows, C, w, b, scale, shift, eps, y_lo)) {
+        fw_set_error("fw_layernorm_mod_split: unsupported width"); return FW_E_UNSUPPORTED; }
     return (int)hipGetLastError();
 }
 

@@ -731,6 +731,181 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4b_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// gemm_bf16_w4d_kernel (round 6 experiment, FW_GEMM_KERNEL=8): gemm_bf16_w4b_kernel with its steady-state LDS-DMA pieces issued as
+// buffer_load ... lds through an SGPR descriptor instead of global_load_lds with a 64-bit address pair.  The vendor library's kernel
+// for these shapes (Custom_Cijk_..._MT256x256x64_MI16x16x1, disassembled from torch's hipblaslt code object: four waves, 128 x
+// v_mfma_f32_16x16x32_bf16 + 32 ds_read_b128 + 16 `buffer_load_dwordx4 ... offen lds` + 3 s_barrier per slab, no ds_write) IS a
+// four-wave LDS-DMA kernel and reaches 1500 TF/s: what blocked w4b's waves is worth re-measuring on this request form.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4d_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int gid = wg / per_group;
+        const int first_m = gid * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        const int in_g = wg - gid * per_group;
+        tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    // DMA pieces (1 KiB = 8 rows x 128 B): wave w streams A pieces 8w..8w+7 (tile rows 64w .. 64w+63) and the same W pieces.
+    const char* abase = (const char*)(p.A + (int64_t)m0 * p.lda);
+    const char* wbase = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    unsigned aoff[8], woff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        aoff[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.lda + chunk * 8) * 2u;
+        woff[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw + chunk * 8) * 2u;
+    }
+    // the pieces of the steady loop: buffer_load ... lds through an SGPR descriptor (the form the vendor's kernel uses; rows past M / N
+    // are out of range of the descriptor), one 32-bit offset register per operand and piece parity, the rest in the scalar offset
+    const long long arem = (long long)(p.M - m0) * p.lda * 2, wrem = (long long)(p.N - n0) * p.ldw * 2;
+    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0,
+                                                       (int)(unsigned)(arem > 0xffffffffLL ? 0xffffffffLL : arem), 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.ldw), 0,
+                                                       (int)(unsigned)(wrem > 0xffffffffLL ? 0xffffffffLL : wrem), 0x00020000);
+    const int pr = lane >> 3, pc = lane & 7;
+    const int va[2] = {pr * (int)p.lda * 2 + ((pc ^ (pr >> 1)) << 4), pr * (int)p.lda * 2 + ((pc ^ ((pr >> 1) | 4)) << 4)};
+    const int vw[2] = {pr * (int)p.ldw * 2 + ((pc ^ (pr >> 1)) << 4), pr * (int)p.ldw * 2 + ((pc ^ ((pr >> 1) | 4)) << 4)};
+    const int astep = __builtin_amdgcn_readfirstlane((int)p.lda * 16), wstep = __builtin_amdgcn_readfirstlane((int)p.ldw * 16);
+#define FW_4D_A(S, KT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, FW_LDS_PTR(smem + (S) * STAGE2 + (wave * 8 + (I)) * 1024), 16, va[(I) & 1], (KT) * (BK * 2) + (wave * 8 + (I)) * astep, 0, 0)
+#define FW_4D_W(S, KT, I) __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, FW_LDS_PTR(smem + (S) * STAGE2 + TM * BK * 2 + (wave * 8 + (I)) * 1024), 16, vw[(I) & 1], (KT) * (BK * 2) + (wave * 8 + (I)) * wstep, 0, 0)
+
+    const int fi = lane & 31, hi = lane >> 5;
+    const int swz = (fi >> 1) & 7;
+    int a_addr[4], b_addr[4];              // byte offsets of this lane's fragment chunk of k-step ks in stage 0 (+ rb * 4096)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = ((2 * ks + hi) ^ swz) << 4;
+        a_addr[ks] = (wm * 128 + fi) * 128 + c;
+        b_addr[ks] = TM * BK * 2 + (wn * 128 + fi) * 128 + c;
+    }
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8_t fa[2][4], fb[2][4];           // [set][row / column block]
+
+    const int nk = p.K / BK;               // >= 4 (launcher)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { FW_GLDS16(abase + aoff[i], smem + (wave * 8 + i) * 1024); FW_GLDS16(wbase + woff[i], smem + TM * BK * 2 + (wave * 8 + i) * 1024); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { FW_GLDS16(abase + BK * 2 + aoff[i], smem + STAGE2 + (wave * 8 + i) * 1024); FW_GLDS16(wbase + BK * 2 + woff[i], smem + STAGE2 + TM * BK * 2 + (wave * 8 + i) * 1024); }
+    fw_wait_vm<16>();
+    FW_BARRIER();
+
+    // One k-step: 16 MFMAs on fragment set CUR, with (READ) the 8 fragment reads of k-step `rks` of stage `rst` into the other set
+    // after MFMAs 0..7 and (NDMA pieces, first one = piece `p0`) LDS-DMA pieces of slab `dk` into stage `dst` dealt out between
+    // the MFMAs; nothing may be reordered.  A global_load_lds_dwordx4 occupies the CU's one texture-address path for 16 cycles
+    // (1 KiB at 64 B/clk) and BLOCKS the issuing wave until it is accepted: four waves issuing their pieces together serialise
+    // behind each other (~60 cycles each, matrix pipe idle -- measured: +1000 cycles per slab, exactly 64 pieces x 16 cycles).  So
+    // the pieces are spread over three k-steps (one per 3 MFMAs) and the waves take DIFFERENT MFMA slots (slot = 3 i + wave % 3)
+    // -- which, measured, changes nothing either way (1100 TF/s spread or bunched): the cost follows the BYTES, see docs/kernels.md.
+    const int dslot = wave % 3;
+    auto kstep = [&](auto cur_tag, auto read_tag, auto dma_tag, int rst, int rks, int dst, int dk) {
+        constexpr int CUR = decltype(cur_tag)::value;
+        constexpr bool READ = decltype(read_tag)::value;
+        constexpr int GB = decltype(dma_tag)::value;            // -1: no DMA in this k-step; else first of its 16 global MFMA slots (0 / 16 / 32)
+        const char* rbase = smem + rst * STAGE2;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[CUR][rb], fb[CUR][nb], acc[rb][nb], 0, 0, 0);
+                const int j = rb * 4 + nb;                      // 0..15
+                if (READ && j < 8) {                            // a0 b0 a1 b1 .. : the last read is 8 MFMAs old at the next k-step
+                    FW_NOMOVE();
+                    if (j & 1) fb[CUR ^ 1][j >> 1] = *(const bf16x8_t*)(rbase + b_addr[rks] + (j >> 1) * 4096);
+                    else fa[CUR ^ 1][j >> 1] = *(const bf16x8_t*)(rbase + a_addr[rks] + (j >> 1) * 4096);
+                    FW_NOMOVE();
+                }
+                if (GB >= 0) {                                  // the 48 MFMA slots of P3, P0, P1 carry the 16 pieces: piece g / 3 in the
+                    const int g = GB + j;                       // wave's own slot (g % 3 == dslot) of every MFMA triple
+                    if (g % 3 == 0) {                           // compile-time slot (every third MFMA): no per-slot branch
+                        const int i = g / 3;                    // 0..15: A pieces 0..7, then W pieces 0..7
+                        FW_NOMOVE();
+                        if (i < 8) { FW_4D_A(dst, dk, i); } else { FW_4D_W(dst, dk, i - 8); }
+                        FW_NOMOVE();
+                    }
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using DN = std::integral_constant<int, -1>;
+    using D0 = std::integral_constant<int, 0>;
+    using D16 = std::integral_constant<int, 16>;
+    using D32 = std::integral_constant<int, 32>;
+
+    // prologue: slab 0 k-steps 0..2 (no DMA: stage 0 is still being read), then the barrier that opens slab 1
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        fa[0][rb] = *(const bf16x8_t*)(smem + a_addr[0] + rb * 4096);
+        fb[0][rb] = *(const bf16x8_t*)(smem + b_addr[0] + rb * 4096);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    kstep(S0{}, T{}, DN{}, 0, 1, 0, 0);
+    kstep(S1{}, T{}, DN{}, 0, 2, 0, 0);
+    kstep(S0{}, T{}, DN{}, 0, 3, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    fw_wait_vm<0>();
+    FW_BARRIER();
+
+    // steady state: T = slab whose k-step 3 is pending in set 1; slab T+1 landed in stage (T+1)&1; slab T+2 goes to stage T&1
+    int Tk = 0;
+    auto body = [&](auto has2_tag) {
+        constexpr bool HAS2 = decltype(has2_tag)::value;
+        const int sn = (Tk + 1) & 1, so = Tk & 1;
+        if (HAS2) {
+            kstep(S1{}, T{}, D0{}, sn, 0, so, Tk + 2);          // P3: MFMA slots  0..15
+            kstep(S0{}, T{}, D16{}, sn, 1, so, Tk + 2);         // P0: MFMA slots 16..31
+            kstep(S1{}, T{}, D32{}, sn, 2, so, Tk + 2);         // P1: MFMA slots 32..47
+        } else {
+            kstep(S1{}, T{}, DN{}, sn, 0, so, 0);
+            kstep(S0{}, T{}, DN{}, sn, 1, so, 0);
+            kstep(S1{}, T{}, DN{}, sn, 2, so, 0);
+        }
+        kstep(S0{}, T{}, DN{}, sn, 3, so, 0);                   // P2: a k-step without DMA lets the last pieces land
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fw_wait_vm<0>();
+        FW_BARRIER();
+        ++Tk;
+    };
+    while (Tk < nk - 2) body(T{});
+    body(F{});                                                  // Tk = nk-2: slab nk-1 k-steps 0..2, no more DMA
+    kstep(S1{}, F{}, DN{}, 0, 0, 0, 0);                         // k-step 3 of the last slab
+    __builtin_amdgcn_s_setprio(0);
+    FW_BARRIER();
+    epilogue_w4(p, smem, acc, wave, wm, wn, fi, hi, lane, m0, n0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // gemm_bf16_w4c_kernel (round 6 experiment, FW_GEMM_KERNEL=7): the four-wave kernel above with the global -> LDS path the vendor
 // library's kernel for these shapes uses -- buffer_load_dwordx4 into VGPRs, ds_write_b128 into the stage -- instead of LDS-DMA.
 // Why: gemm_bf16_w4b_kernel's finding is that a global_load_lds BLOCKS the issuing wave until the texture-address path accepts it
@@ -1004,6 +1179,8 @@ extern "C" int fw_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, i
         // 6 ... = the two-slot ping-pong kernels of round 4 (gemm_pp.hip)
         if (kern == 5) {
             hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
+        } else if (kern == 8 && p.lda < (1 << 21) && p.ldw < (1 << 21)) {      // round-6 experiment: four waves, descriptor LDS-DMA
+            hipLaunchKernelGGL(gemm_bf16_w4d_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (kern == 7 && p.lda < (1 << 21) && p.ldw < (1 << 21)) {      // round-6 experiment: four waves, VGPR-staged loads
             hipLaunchKernelGGL(gemm_bf16_w4c_kernel, dim3((unsigned)nwg), dim3(256), 0, st, p);
         } else if (kern >= 6 && fw_launch_gemm_pp(p, kern, fw_get_option(FW_OPT_GEMM_VAR), st)) {

@@ -157,6 +157,11 @@ class FusionEngine:
             self.ctl_res2 = lin(ca + "residual_blocks.0.conv2.weight", ca + "residual_blocks.0.conv2.bias")
         self.head_mod = ops.to_f32(g(pd + "head.modulation").reshape(2, cfg.dim))
         self.head = lin(pd + "head.head.weight", pd + "head.head.bias")
+        # round 6: the head's LayerNorm keeps its bf16 rounding remainder (ops.layernorm_split) and the 5120 -> 64 head GEMM runs on
+        # both parts -- that ONE store was a third of the forward's bf16 floor (per-site ablation, docs/parity.md: noise_pred 3.0e-3
+        # -> 2.5e-3 for two tiny launches).  split_head_norm = False: the round-1..5 form (A/B, tests)
+        self.split_head_norm = hasattr(ops, "layernorm_split")
+        self.head_lo = type(self.head)(self.head.w, None) if self.split_head_norm else None      # same weights, no bias: + W lo
         self.dit = [self._pack_dit(b, g, lin, lin_cat) for b in range(cfg.num_layers)]
 
         self.proj = lin("vggt.projection_head.weight", "vggt.projection_head.bias")
@@ -830,8 +835,13 @@ class FusionEngine:
         cfg, ops, sh = self.cfg, self.ops, self.shard
         F, h, w, L = st.F, st.h, st.w, st.L
         hm = ops.modulation_tables(self.head_mod.unsqueeze(0), st.t)[0]            # head.modulation + t (wan_video_dit.py:352-353)
-        xn = ops.layernorm(st.xs, scale=hm[1], shift=hm[0], eps=cfg.eps)
-        hd_out = ops.linear(xn, self.head, out_f32=True)                                       # [L(local), 64]
+        if self.split_head_norm:
+            xn, xn_lo = ops.layernorm_split(st.xs, scale=hm[1], shift=hm[0], eps=cfg.eps)
+            hd_out = ops.linear(xn, self.head, out_f32=True)                                   # [L(local), 64] = W hi + b
+            ops.linear(xn_lo, self.head_lo, res=hd_out, out_f32=True, out=hd_out)              # + W lo
+        else:
+            xn = ops.layernorm(st.xs, scale=hm[1], shift=hm[0], eps=cfg.eps)
+            hd_out = ops.linear(xn, self.head, out_f32=True)                                   # [L(local), 64]
         if sh is not None:
             hd_out = sh.all_gather_rows(hd_out, sh.dit_counts)
         outs = [ops.unpatchify(hd_out[i * L:(i + 1) * L], F, h, w, out_dtype) for i in range(st.nb)]

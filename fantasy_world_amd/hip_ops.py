@@ -30,6 +30,7 @@ SYMBOLS = [
     "fw_fp8_quant_rows", "fw_gemm_fp8",
     "fw_row_sumsq", "fw_qk_prep_tp", "fw_residual_add", "fw_cfg_euler_step",
     "fw_qk_prep_fp8", "fw_v_transpose_e4m3", "fw_row_absmax", "fw_fp8_quant_rows_amax", "fw_modulation_tables",
+    "fw_layernorm_mod_split",
 ]
 
 _lib = None
@@ -98,6 +99,7 @@ def load_library(path: str = LIB_PATH, cache: bool = True):
         "fw_row_absmax": [vp, i64, i32, i32, vp, vp],
         "fw_fp8_quant_rows_amax": [vp, i64, vp, i64, vp, vp, i32, i32, vp],
         "fw_modulation_tables": [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp],
+        "fw_layernorm_mod_split": [vp, i64, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -281,6 +283,19 @@ class HipOps:
                                          _ptr(w), _ptr(b), _ptr(scale), _ptr(shift), float(eps), self._stream()),
                "fw_layernorm_mod")
         return out
+
+    def layernorm_split(self, x, w=None, b=None, scale=None, shift=None, eps=1e-6):
+        """LayerNorm (+ affine, + modulation) of an fp32 stream with the bf16 rounding remainder kept: -> (hi, lo), both bf16, hi + lo =
+        the fp32 result to ~16 bits (fw_layernorm_mod_split; the head's LayerNorm: a third of the forward's bf16 floor)."""
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        self._check_dev(x, w, b, scale, shift)
+        rows, C = x.shape
+        hi = torch.empty(rows, C, dtype=torch.bfloat16, device=self.device)
+        lo = torch.empty(rows, C, dtype=torch.bfloat16, device=self.device)
+        _check(self.lib.fw_layernorm_mod_split(x.data_ptr(), x.stride(0), hi.data_ptr(), lo.data_ptr(), hi.stride(0), rows, C,
+                                               _ptr(w), _ptr(b), _ptr(scale), _ptr(shift), float(eps), self._stream()),
+               "fw_layernorm_mod_split")
+        return hi, lo
 
     def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
                 ext_sumsq=None, norm_width=None, out8=None, head_stride8=None):

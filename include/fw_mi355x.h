@@ -156,6 +156,13 @@ int fw_layernorm_mod(const void* x, int64_t ldx, int x_dtype, uint16_t* y, int64
                      int rows, int C, const float* w, const float* b,
                      const float* scale, const float* shift, float eps, void* stream);
 
+/* fw_layernorm_mod with the rounding remainder kept: y = y_hi + y_lo, y_hi = bf16(y), y_lo = bf16(y - y_hi) (round 6).  For the ONE
+ * LayerNorm whose bf16 rounding reaches the output without a residual stream behind it -- the one in front of the output head
+ * (DIT21:350-357): a third of the whole forward's bf16 floor (docs/parity.md, per-site ablation).  The head's 5120 -> 64 GEMM then
+ * runs on both parts.  x fp32 [rows][C] (ldx), y_hi / y_lo bf16 (ldy); C % 256 == 0. */
+int fw_layernorm_mod_split(const float* x, int64_t ldx, uint16_t* y_hi, uint16_t* y_lo, int64_t ldy, int rows, int C,
+                           const float* w, const float* b, const float* scale, const float* shift, float eps, void* stream);
+
 /*
  * In-place q/k post-projection: normalisation + rotary embedding on a [rows][heads*hd] bf16 slice (ldx).
  *   norm_mode: FW_NORM_*; norm_w (and norm_b for LN_HEAD) fp32.

@@ -251,6 +251,10 @@ SIZED_CASES = {
     # [1,16,21,42,74]): 21 x 37 = 777 tokens per frame -- odd in both directions, L = 16317 (not a multiple of any tile size), 782
     # VGGT tokens per frame, L2 = 16422 -- the shape a user of the unmodified script gets first (round 4)
     "wan21_cli_l2_f21_42x74": (dict(num_layers=2, start_index=1), (21, 42, 74), 996.0, 512, 64, False),
+    # BASELINE.json configs[4] token grid (Wan2.2, 121f x 720p -> latents [1,16,31,90,160], L = 111600, L2 = 111755): round 6 -- the live
+    # fp32 reference forward at this size costs the GPU suite 315 s per run (tests/test_config5_gpu.py, now opt-in); as a golden it
+    # is ~35 CPU-minutes ONCE here (FW_GOLDEN_SKIP_ORACLE=1 skips the CPU restatement's own forward at this size)
+    "wan22_cfg5_l2_f31_90x160": (dict(num_layers=2, start_index=1), (31, 90, 160), 996.0, 512, 64, False),
 }
 
 
@@ -296,17 +300,18 @@ def main_sized(only):
         t_ref = time.time() - t0
         print(f"[{name}] reference forward {t_ref:.1f}s (L = {L}, L2 = {L2})", flush=True)
         del model
-        col = {}
-        t0 = time.time()
-        orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
-                                      ins["plucker_fea"], ins["plucker_context_lens"], collect=col,
-                                      control_camera_latents_input=ins.get("control_camera_latents_input"))
-        print(f"[{name}] oracle forward {time.time()-t0:.1f}s", flush=True)
         last = cfg.num_layers - 1
-        print(f"   oracle vs reference  noise_pred     rel-L2 = {rel(orc, out):.3e}")
-        print(f"   oracle vs reference  x_after_pcb    rel-L2 = {rel(col['x_after_pcb'][rows_dit], cap['x_blocks'][cfg.start_index - 1]):.3e}")
-        print(f"   oracle vs reference  x_final        rel-L2 = {rel(col['x_final'][rows_dit], cap['x_blocks'][last]):.3e}")
-        print(f"   oracle vs reference  tokens_final   rel-L2 = {rel(col['tokens_final'].reshape(L2, -1)[rows_agg], cap['tok_blocks'][cfg.n_irg - 1]):.3e}")
+        if os.environ.get("FW_GOLDEN_SKIP_ORACLE", "0") != "1":
+            col = {}
+            t0 = time.time()
+            orc = fw_oracle.joint_forward(W, cfg, ins["x"], ins["timestep"], ins["context"], ins["clip_feature"], ins["y"],
+                                          ins["plucker_fea"], ins["plucker_context_lens"], collect=col,
+                                          control_camera_latents_input=ins.get("control_camera_latents_input"))
+            print(f"[{name}] oracle forward {time.time()-t0:.1f}s", flush=True)
+            print(f"   oracle vs reference  noise_pred     rel-L2 = {rel(orc, out):.3e}")
+            print(f"   oracle vs reference  x_after_pcb    rel-L2 = {rel(col['x_after_pcb'][rows_dit], cap['x_blocks'][cfg.start_index - 1]):.3e}")
+            print(f"   oracle vs reference  x_final        rel-L2 = {rel(col['x_final'][rows_dit], cap['x_blocks'][last]):.3e}")
+            print(f"   oracle vs reference  tokens_final   rel-L2 = {rel(col['tokens_final'].reshape(L2, -1)[rows_agg], cap['tok_blocks'][cfg.n_irg - 1]):.3e}")
         golden = {"noise_pred": out.float().contiguous(), "rows_dit": rows_dit, "rows_agg": rows_agg,
                   "x_after_pcb": cap["x_blocks"][cfg.start_index - 1].float(), "x_final": cap["x_blocks"][last].float(),
                   "tokens_final": cap["tok_blocks"][cfg.n_irg - 1].float()}

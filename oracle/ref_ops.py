@@ -44,6 +44,7 @@ class TorchRefOps:
     fp32_sites = ()
     only_sites = None
     emulate_p = False
+    site_suffix = ":blk"        # appended to the LayerNorm site name; the ablation sets ":head" around the engine's epilogue
 
     def _r(self, t, site="other"):
         if not self.emulate_bf16:
@@ -128,7 +129,18 @@ class TorchRefOps:
             y = y * (1.0 + scale)
         if shift is not None:
             y = y + shift
-        return self._r(y, f"ln:C{x.shape[-1]}")
+        return self._r(y, f"ln:C{x.shape[-1]}{self.site_suffix}")
+
+    def layernorm_split(self, x, w=None, b=None, scale=None, shift=None, eps=1e-6):
+        """fw_layernorm_mod_split: (hi, lo) with hi = bf16(y), lo = bf16(y - hi); without bf16 emulation hi = y, lo = 0."""
+        y = F.layer_norm(x.to(torch.float32), (x.shape[-1],), w, b, eps)
+        if scale is not None:
+            y = y * (1.0 + scale)
+        if shift is not None:
+            y = y + shift
+        site = f"ln:C{x.shape[-1]}{self.site_suffix}"
+        hi = self._r(y, site)
+        return hi, self._r(y - hi, site)
 
     def qk_prep(self, x, heads, hd, norm=None, norm_w=None, norm_b=None, eps=1e-6, rope=None, table=None, out_scale=1.0,
                 ext_sumsq=None, norm_width=None, out8=None, head_stride8=None):

@@ -130,7 +130,9 @@ class ParityLog:
         # 1.2e-3 -> 3.9e-3 under a 4e-3 bound -- into a failure.  Only applied on a GPU run.
         self.tight = {}
         path = os.path.join(GOLDEN_DIR, "parity_bounds_gpu.json")
-        if os.path.exists(path) and torch.cuda.is_available():
+        # FW_PARITY_TIGHT=0: physical bounds only -- the run that REGENERATES the tight bounds after a deliberate bit-moving change
+        # (compiler flags, a kernel edit; tests/test_hip_ops.py::test_production_kernel_outputs_match_committed_digests names those)
+        if os.path.exists(path) and torch.cuda.is_available() and os.environ.get("FW_PARITY_TIGHT", "1") != "0":
             import json
             self.tight = json.load(open(path))["bounds"]
 

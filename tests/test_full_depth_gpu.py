@@ -238,6 +238,10 @@ def _yardstick(model, cfg, ins, want, hip, parity):
 # Which bf16 STORES make the floor?  Groups of rounding sites of oracle/ref_ops.py (prefixes) at the 14B widths.
 ABLATION_SITES = {
     "layernorm_outputs_dit": ("ln:C5120",),
+    # round 6, second pass: the ONE LayerNorm in front of the output head (its rounding reaches noise_pred without a residual stream
+    # to average it) apart from the 160 inside the blocks
+    "layernorm_output_in_front_of_the_head_only": ("ln:C5120:head",),
+    "layernorm_outputs_inside_the_blocks_only": ("ln:C5120:blk",),
     "dit_qkv_projection_and_qk_pass": ("linear_out:N15360:K5120", "qk:hd128"),
     "dit_self_attention_output": ("attn_o:hd128:long",),
     "dit_ffn_hidden": ("linear_out:N13824:K5120",),
@@ -256,6 +260,15 @@ def _ablation(model, cfg, ins, want, eng, floor_all, parity):
     PV the way the HIP kernels do (not part of the default floor).  Recorded under full_depth/.../ablation/*; ranked table in docs/parity.md."""
     ops = eng.ops
     wout = want[0].float()
+    epi = eng._epilogue
+
+    def epilogue(*a, **k):           # the head's LayerNorm is a site of its own
+        ops.site_suffix = ":head"
+        try:
+            return epi(*a, **k)
+        finally:
+            ops.site_suffix = ":blk"
+    eng._epilogue = epilogue
 
     def run():
         out, _, _ = _hip_forward(model, eng, cfg, ins, False)
@@ -349,6 +362,11 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
                     row[f"tok@{b}"] = parity.check(f"{tag}/vggt_stream_after_block_{b}_{what}", rel_l2(bcap["tok"][b], acap["tok"][b]),
                                                    FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
             print(tag, {k: f"{v:.2e}" for k, v in row.items()}, flush=True)
+            # and the whole fp8-attention option (DiT self-attention + bicross) against the engine with bf16 attention everywhere: the
+            # quantity the stated tolerance is written on
+            both = parity.check(f"full_depth_fp8/wan22/{name}/fp8_dit_and_bicross_attention_vs_bf16_attention_engine/noise_pred",
+                                rel_l2(bout.float(), got8[name][0].float()), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)
+            print(f"full_depth_fp8/wan22/{name} fp8 DiT + bicross attention vs bf16 attention (fp8 linears in both): noise_pred {both:.2e}", flush=True)
 
     assert ref_harness.swap_fp8_linears(model, cfg.start_index) == 40 * len(ref_harness.FP8_SITES)
     for name, ins in inputs.items():

@@ -804,3 +804,17 @@ def test_production_kernel_outputs_match_committed_digests(ops):
                        "gpurun_out/" + DIGESTS + " to tests/golden/ and say why in the commit")
     if missing:
         pytest.skip("no committed digest for " + ", ".join(missing) + " (recorded in gpurun_out/" + DIGESTS + ")")
+
+
+def test_layernorm_split_keeps_the_rounding_remainder(ops, ref):
+    """fw_layernorm_mod_split (round 6): hi = the bits fw_layernorm_mod writes, hi + lo = the fp32 LayerNorm to ~16 bits -- the form the
+    head's LayerNorm uses (its bf16 rounding alone was a third of the forward's bf16 floor: docs/parity.md)."""
+    for rows, C in ((4100, 5120), (33, 1024)):
+        g = torch.Generator().manual_seed(41)
+        x = torch.randn(rows, C, generator=g).cuda() * 3 + 0.5
+        scale, shift = torch.randn(C, generator=g).cuda() * 0.3, torch.randn(C, generator=g).cuda()
+        hi, lo = ops.layernorm_split(x, scale=scale, shift=shift, eps=1e-6)
+        assert torch.equal(hi, ops.layernorm(x, scale=scale, shift=shift, eps=1e-6))
+        want = ref.layernorm(x.cpu(), scale=scale.cpu(), shift=shift.cpu(), eps=1e-6)
+        e_hi, e_split = rel_l2(hi.float(), want), rel_l2(hi.float() + lo.float(), want)
+        assert e_hi > 1e-3 and e_split < 2e-5, (e_hi, e_split)

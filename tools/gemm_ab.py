@@ -18,6 +18,7 @@ ap.add_argument("--iters", type=int, default=6)
 ap.add_argument("--short-k", action="store_true", help="the K <= 2048 shapes of the VGGT / bicross / adapter GEMMs instead of the DiT ones")
 ap.add_argument("--square", action="store_true", help="the programming guide's calibration shapes 4096^3 / 8192^3 (+ the DiT qkv shape)")
 ap.add_argument("--uniform", action="store_true", help="uniform [-1, 1) operands (the guide's random fill) instead of normal")
+ap.add_argument("--fp8", action="store_true", help="the fp8 linear (fw_gemm_fp8 on pre-quantised rows): kernel 9 = two-slot (round 6), 4 = four-slot")
 ap.add_argument("--zeros", action="store_true", help="zero-filled operands: the same instruction stream at a fraction of the switching power (DVFS check)")
 args = ap.parse_args()
 # "blas" = the vendor library behind torch.matmul on the SAME operands in the SAME interleaved rounds (a yardstick of what the box
@@ -40,6 +41,9 @@ for (M, N, K, tag, res) in SHAPES:
     if args.zeros:
         x.zero_()
         lin.w.zero_()
+    if args.fp8:
+        lin = ops.pack_linear(lin.w.float(), lin.b, fp8=True)
+        x = ops.quantize_fp8_rows(x)            # (e4m3 rows, scale): the GEMM alone is timed
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     xs = torch.randn(M, N, device="cuda") if res else None
     gate = torch.randn(N, device="cuda") if res else None
