@@ -147,7 +147,7 @@ def attention_measured(hd):
     under these kernels: 1.5-1.7 of 2.4 GHz).  busy x ghz / 2.4 is the fraction of the 2.5 PF peak those two numbers predict; the
     remaining (1 - busy) of the cycles have no MFMA in flight (docs/kernels.md, "where the other cycles go").  Replaces the round-3/4
     `roofline_cap` model (8 hd MFMA + 533 VALU cycles per tile, "0.658 at 1.95 GHz"), which the round-4 counters contradicted."""
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "attn_counters.json")) as f:
                 rec = json.load(f)["hd%d" % hd]
@@ -477,7 +477,7 @@ def main():
     headline = (not wan22 and args.layers == 40 and (args.frames, args.height, args.width) == (81, 480, 832)
                 and args.precision == "bf16")
     if headline and sp == 1:
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
                     traffic = nb * float(json.load(f)["attention_hd128_self"]["traffic_bytes_per_launch"])    # merged CFG: batch 2 per launch

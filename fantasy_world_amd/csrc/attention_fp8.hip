@@ -958,7 +958,9 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
                      (uint64_t)(Lk + 6 * KVB) * (uint64_t)ldk >= 0x7fffffffull;
     if (var == 8) hipLaunchKernelGGL(attention_fp8_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
     else if (var == 9 || big) hipLaunchKernelGGL(attention_fp8_pp_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
-    else if (var == 10) hipLaunchKernelGGL((attention_fp8_sp_kernel<1>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    // (FW_ATTN_VAR=10, the in-phase arm with fp32 row sums on the vector pipe, is gone since round 6: it was the slower arm, and under
+    //  -fno-associative-math its error at 64+ tiles grew from 5.4e-2 to 7.0e-2 against the fp32 softmax while every other arm kept its
+    //  round-5 bits -- not worth a fourth instantiation with 440 B of scratch; 10 now selects the default kernel)
     else if (var == 11) hipLaunchKernelGGL((attention_fp8_sp_kernel<2>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_fp8_sp_kernel<0>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();

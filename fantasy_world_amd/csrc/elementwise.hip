@@ -251,6 +251,12 @@ static bool launch_ln_wave(hipStream_t st, const void* x, int64_t ldx, uint16_t*
 // owns up to QK_MAXC chunks of 8 consecutive channels; the normalised row is parked in LDS (fp32) so the rotary
 // partner (i^1 for interleaved pairs, i +- hd/4 for the 2-D rotate-half form) can be fetched by any thread.
 // ------------------------------------------------------------------------------------------------------------
+// a * c -/+ b * s of the rotary embedding with the contraction SPELLED OUT (one product rounded, the other fused): left to
+// -ffp-contract=fast the compiler picked the fused operand per INSTANTIATION, and the e4m3-writing form of the DiT q/k pass differed
+// from the bf16 form in the last fp32 bit of some elements (round 6: fw_qk_prep_fp8 must return the bits of cast(fw_qk_prep(.)))
+__device__ __forceinline__ float qk_rot_sub(float a, float c, float b, float s) { return __builtin_fmaf(a, c, -(b * s)); }
+__device__ __forceinline__ float qk_rot_add(float a, float c, float b, float s) { return __builtin_fmaf(a, c, b * s); }
+
 // fw_qk_prep_fp8: the 8 results of a chunk as e4m3 bytes -- rounded to bf16 first (the value the bf16 form stores), then cast raw like
 // fw_fp8_quant_rows(raw = 1), so the fused form returns the bits of the two-pass form.
 __device__ __forceinline__ u32x2_t qk_pack_e4m3(const float* o) {
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                 v[i][2 * j + 1] = __uint_as_float(raw[j] & 0xffff0000u);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+            for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(v[i][j], v[i][j], ss);
         }
     }
     if (norm_mode == FW_NORM_RMS_FULL) {
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
             if (ch < nch) {
                 const int d0 = (ch * 8) & 63;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mean) * r * nw[d0 + j] + nb[d0 + j];
+                for (int j = 0; j < 8; ++j) v[i][j] = __builtin_fmaf((v[i][j] - mean) * r, nw[d0 + j], nb[d0 + j]);
             }
         }
     }
@@ -382,8 +388,8 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                 for (int j = 0; j < 4; ++j) {
                     const float cs = trow[(e0 / 2 + j) * 2], sn = trow[(e0 / 2 + j) * 2 + 1];
                     const float a = v[i][2 * j], bq = v[i][2 * j + 1];
-                    of[2 * j] = a * cs - bq * sn;
-                    of[2 * j + 1] = a * sn + bq * cs;
+                    of[2 * j] = qk_rot_sub(a, cs, bq, sn);
+                    of[2 * j + 1] = qk_rot_add(a, sn, bq, cs);
                 }
                 if (o8r) { qk_store_e4m3(o8r, ch * 8, hd, hs8, of); continue; }
                 u32x4_t o4 = {pack_bf16x2(of[0], of[1]), pack_bf16x2(of[2], of[3]), pack_bf16x2(of[4], of[5]), pack_bf16x2(of[6], of[7])};
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(uint16_t* __restrict__ x, 
                 const int pidx = hsel * quarter + (lo ? wi : wi - quarter);
                 const float cs = trow[pidx * 2], sn = trow[pidx * 2 + 1];
                 const float partner = rowbuf[base + j + (lo ? quarter : -quarter)];
-                o[j] = lo ? (v[i][j] * cs - partner * sn) : (v[i][j] * cs + partner * sn);
+                o[j] = lo ? qk_rot_sub(v[i][j], cs, partner, sn) : qk_rot_add(v[i][j], cs, partner, sn);
             }
             if (o8r) { qk_store_e4m3(o8r, base, hd, hs8, o); continue; }
             u32x4_t o4 = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             v[i][2 * j + 1] = __uint_as_float(raw[i][j] & 0xffff0000u);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+        for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(v[i][j], v[i][j], ss);
     }
     if (NORM == FW_NORM_RMS_FULL) {
         const float r = ext_ss ? rsqrtf(ext_ss[row] / (float)norm_width + eps) : rsqrtf(wave_sum(ss) / (float)width + eps);
@@ -505,8 +511,8 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             const f32x4_t b0 = *(const f32x4_t*)(nb + d0), b1 = *(const f32x4_t*)(nb + d0 + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[i][j] = (v[i][j] - mean) * r * w0[j] + b0[j];
-                v[i][4 + j] = (v[i][4 + j] - mean) * r * w1[j] + b1[j];
+                v[i][j] = __builtin_fmaf((v[i][j] - mean) * r, w0[j], b0[j]);
+                v[i][4 + j] = __builtin_fmaf((v[i][4 + j] - mean) * r, w1[j], b1[j]);
             }
         }
     }
@@ -539,10 +545,10 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
             const int e0 = (ch * 8) % hd;
             f32x4_t t0 = {1.f, 0.f, 1.f, 0.f}, t1 = {1.f, 0.f, 1.f, 0.f};
             if (ch < nch) { t0 = *(const f32x4_t*)(trow + e0); t1 = *(const f32x4_t*)(trow + e0 + 4); }
-            o[0] = v[i][0] * t0[0] - v[i][1] * t0[1]; o[1] = v[i][0] * t0[1] + v[i][1] * t0[0];
-            o[2] = v[i][2] * t0[2] - v[i][3] * t0[3]; o[3] = v[i][2] * t0[3] + v[i][3] * t0[2];
-            o[4] = v[i][4] * t1[0] - v[i][5] * t1[1]; o[5] = v[i][4] * t1[1] + v[i][5] * t1[0];
-            o[6] = v[i][6] * t1[2] - v[i][7] * t1[3]; o[7] = v[i][6] * t1[3] + v[i][7] * t1[2];
+            o[0] = qk_rot_sub(v[i][0], t0[0], v[i][1], t0[1]); o[1] = qk_rot_add(v[i][0], t0[1], v[i][1], t0[0]);
+            o[2] = qk_rot_sub(v[i][2], t0[2], v[i][3], t0[3]); o[3] = qk_rot_add(v[i][2], t0[3], v[i][3], t0[2]);
+            o[4] = qk_rot_sub(v[i][4], t1[0], v[i][5], t1[1]); o[5] = qk_rot_add(v[i][4], t1[1], v[i][5], t1[0]);
+            o[6] = qk_rot_sub(v[i][6], t1[2], v[i][7], t1[3]); o[7] = qk_rot_add(v[i][6], t1[3], v[i][7], t1[2]);
         } else if (ROPE == FW_ROPE_HALF2D) {
             // hd == 64: chunk k = ch & 7 of the head; y half = chunks 0..3, x half = 4..7; inside a half the first two
             // chunks are the "lo" 16 elements, partner chunk = k ^ 2 (lane ^ 2); table pair index = hsel*16 + (k&1)*8 + j
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(256) void qk_prep_wave_kernel(uint16_t* __restrict_
                 const float partner = __shfl_xor(v[i][j], 2, 64);
                 float cs = 1.f, sn = 0.f;
                 if (ch < nch) { cs = trow[(pidx + j) * 2]; sn = trow[(pidx + j) * 2 + 1]; }
-                o[j] = lo ? (v[i][j] * cs - partner * sn) : (v[i][j] * cs + partner * sn);
+                o[j] = lo ? qk_rot_sub(v[i][j], cs, partner, sn) : qk_rot_add(v[i][j], cs, partner, sn);
             }
         } else {
 #pragma unroll

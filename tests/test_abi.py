@@ -190,7 +190,7 @@ def test_fp8_attention_row_maximum_reads_mfma_results_behind_a_compiler_visible_
     every attention_fp8_sp_kernel instantiation is checked -- each v_max3 group is preceded by a v_readfirstlane of a register the group
     reads, with no MFMA that writes that block in between (the compiler pads that read with the s_nop the hazard needs)."""
     kernels = {k: v for k, v in _disassemble("attention_fp8").items() if "attention_fp8_sp_kernel" in k}
-    assert len(kernels) >= 3, sorted(kernels)
+    assert len(kernels) >= 2, sorted(kernels)          # <0> (default, skewed) and <2> (in phase); the VALU-sum arm <1> was removed in round 6
     groups = 0
     for name, ins in kernels.items():
         for i, text in enumerate(ins):
@@ -211,4 +211,4 @@ def test_fp8_attention_row_maximum_reads_mfma_results_behind_a_compiler_visible_
                 m = re.match(r"v_mfma\S* v\[(\d+):(\d+)\]", b)
                 assert not (m and int(m.group(1)) <= int(reg) <= int(m.group(2))), (name[:80], i, b)
             groups += 1
-    assert groups >= 3 * 5, groups
+    assert groups >= 2 * 5, groups
