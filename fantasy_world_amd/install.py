@@ -217,7 +217,9 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     BASELINE config 5, "fp8 attention + FFN"): the DiT self-attention on e4m3 q / k / v / probabilities as well.  The reference
     defines fp8 for nn.Linear only, so this option has NO reference semantics to be exact against: its stated, test-enforced
     tolerance is 2e-2 rel-L2 of noise_pred against the same engine with bf16 attention (measured 1.35e-2 at 40 / 24 / 24 blocks,
-    INTEGRATION.md).  Both options work on one GPU and under either multi-GPU partition (`topo`).
+    INTEGRATION.md).  Both options work on one GPU and under either multi-GPU partition (`topo`).  `fp8_attention="bicross"`
+    (one GPU; round-6 experiment): additionally the two directions of the bicross attention through the same kernel on zero-padded
+    heads -- measured 1.36e-2 against bf16 attention everywhere at 40 / 24 / 24 blocks, the same stated 2e-2.
 
     Several GPUs (one process per GPU, every process running the SAME reference script on the same inputs): pass
     `topo=fantasy_world_amd.parallel.init_topology()` (or a bare `shard=SequenceShard(...)`).  The forward is then
