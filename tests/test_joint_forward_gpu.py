@@ -335,6 +335,17 @@ def test_hip_sequence_shard_over_rccl_single_rank_group(case_l3):
         got, _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
         torch.cuda.synchronize()
         assert torch.equal(got, want)
+        del eng
+        # round 6: BASELINE config 5's arithmetic through the same transport -- the head exchange then carries e4m3 BYTES (uint8
+        # all_to_all_single over RCCL) and the TP-style MAX all-reduce of the fp8 row maxima runs on the device
+        opts = dict(precision="fp8", fp8_attention=True)
+        want8, _ = FusionEngine(case.cfg, case.weights.__getitem__, ops, **opts).joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
+        got8, _ = FusionEngine(case.cfg, case.weights.__getitem__, ops, shard=SequenceShard(0, 1), **opts).joint_forward(
+            ins["x"], ins["timestep"], ins["context"], **kw)
+        amax = torch.tensor([1.0, 5.0, 3.0], device="cuda")
+        dist.all_reduce(amax, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        assert torch.equal(got8, want8) and amax.tolist() == [1.0, 5.0, 3.0]
     finally:
         if created:
             dist.destroy_process_group()
