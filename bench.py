@@ -509,7 +509,7 @@ def main():
                    "cfg_merged_in_one_pass": bool(args.merge_cfg and world == 1),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
-        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_sp_kernel<0>" if fp8_attn else "attention_sp_kernel<128, 65>") + " (DiT self-attention, one launch per block"
+        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_sp_kernel<19974>" if fp8_attn else "attention_sp_kernel<128, 65>") + " (DiT self-attention, one launch per block"
                                + ("" if n_groups == 1 else f", in {n_groups} head groups under the sequence shard")
                                + ("" if topo.tp is None else f", {cfg.num_heads // sp} of {cfg.num_heads} heads per tensor-parallel rank") + ")",
                      # peak / frac follow the DOMINANT KERNEL's arithmetic type: the e4m3 attention kernel is priced against the dense

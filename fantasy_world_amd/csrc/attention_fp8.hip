@@ -603,10 +603,34 @@ __device__ __forceinline__ float fw8_max16(const f32x16_t& v) {
 // a SIMD always has one wave on the vector side and one on the matrix side.  8-slot rings (128 KiB) keep the tile requests clear of
 // both groups' reads: K(t+5) / Vt(t+3) are requested at the top of tile t into the slots of K(t-3) / Vt(t-5), and the wait before a
 // barrier leaves the four newest requests in flight.
+// THE EXPONENTIAL IS AN INTEGER CONVERSION (VAR bit 2, the default since round 6).  The e4m3 byte of 2^x, for x + 7 >= 1, is
+//   (floor(x) + 7) << 3 | round(8 (2^frac(x) - 1));       and with 2^f ~ 1 + f on [0, 1) that is just    round(8 (x + 7)):
+// the byte IS the fixed-point logarithm.  So with the scores produced in units of 1/8 (the QK^T block scale is 2^3 larger) and the shift
+// carrying the bias (M' = 8 m - 56 rides in the accumulator input of the QK^T MFMA like M did), P is ONE v_cvt_pk_u8_f32 per score
+// (round to nearest even, saturating at 0 -- masked keys, NaN -- and 255: tools/probes/cvt_pk_u8_probe.hip pins that on the device) instead of a
+// v_exp_f32 plus half a v_cvt_pk_fp8_f32: 32 vector instructions per tile and wave instead of 48, none of them transcendental.
+// What it costs in accuracy: 1 + f overestimates 2^f by up to 6.1 % (0 at both ends of a binade); a constant factor cancels against the
+// row sum, which the ones-MFMA takes from the SAME bytes, so what is left is a +-3 % ripple on top of e4m3's own +-3 % rounding of P --
+// and both are small beside the e4m3 rounding of q, k and v (tests/test_fp8_gpu.py: against the fp32 softmax 5.8e-2 instead of 5.4e-2 on
+// random data, where an UNROUNDED P gives 4.8e-2).  Below the normal range (x + 7 < 1, weights under 2^-13 of the row's largest) the
+// bytes 0..7 decode as b 2^-9: monotone, within the subnormal spacing of the exact form.  FW_ATTN_VAR=12 / 13 select the exact-exponential
+// arms (skewed / in phase) for the A/B (fw_attention_fp8 below lists all of them).
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     constexpr bool VALU_SUM = (VAR & 1) != 0;
     constexpr bool SKEW = (VAR & 2) == 0;
+    constexpr bool LIN = (VAR & 4) != 0;
+    // TIMING-ONLY knock-outs (builds with -DFW8_KNOCKOUTS, tools/attn_fp8_knockout.py; results are wrong by construction): what each
+    // part of the tile costs where it sits
+    constexpr bool NOBAR = (VAR & 8) != 0, NOMAX = (VAR & 16) != 0, NOCVT = (VAR & 32) != 0, NOSUM = (VAR & 64) != 0;
+    constexpr bool NOLDS = (VAR & 128) != 0, NOREQ = (VAR & 256) != 0;
+    constexpr bool V2 = (VAR & 512) != 0;         // round 6: the tile body in two basic blocks (below)
+    constexpr bool REQ_PV = (VAR & 1024) != 0;    // V2: the tile requests ride between the PV MFMAs instead of opening the tile
+    constexpr bool BAR2 = (VAR & 2048) != 0;      // V2: one barrier per TWO steady tiles
+    constexpr bool UNR8 = (VAR & 16384) != 0;     // V2 + BAR2: the steady loop unrolled by the ring depth (slot offsets become immediates)
+    // the shift in the units of the score registers: the row's largest P is 2^7 when the shift is set (TOP) and the shift moves when a
+    // score would pass 2^8 (OVF); UNIT = score units per power of two
+    constexpr float TOP = LIN ? 112.0f : 7.0f, OVF = LIN ? 120.5f : 8.0f, UNIT = LIN ? 8.0f : 1.0f;
     __shared__ __attribute__((aligned(16))) char smem[RING_SP * (K8_TILE + V8_TILE)];      // 128 KiB
     constexpr int V_BASE = RING_SP * K8_TILE;
 
@@ -642,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     }
     const int nt = (p.Lk + KVB - 1) / KVB;
     const bool ragged = (p.Lk & (KVB - 1)) != 0;
-    const int qs = p.q_scale_e8m0;
+    const int qs = LIN ? p.q_scale_e8m0 + 0x03030303 : p.q_scale_e8m0;        // LIN: scores in eighths (E8M0 exponent + 3 in every byte)
 
     // ---- tile requests: one 1 KiB K piece (8 key rows) and one 1 KiB Vt piece (16 d rows) per wave and tile, through descriptors over
     // this (batch, head)'s K rows / Vt rows: lane offset in a VGPR, the tile's byte offset is the scalar offset; rows past the last key
@@ -656,10 +680,12 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)vbytes, 0x00020000);
     const int k_tile_stride = KVB * (int)p.ldk;
     auto issue_k = [&](int t, int slot) __attribute__((always_inline)) {
+        if (NOREQ && t > 4) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, FW_LDS_PTR(smem + (slot & (RING_SP - 1)) * K8_TILE + wave * 1024), 16, koff,
                                                  t * k_tile_stride, 0, 0);
     };
     auto issue_v = [&](int t, int slot) __attribute__((always_inline)) {
+        if (NOREQ && t > 2) return;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, FW_LDS_PTR(smem + V_BASE + (slot & (RING_SP - 1)) * V8_TILE + wave * 1024), 16, voff,
                                                  t * KVB, 0, 0);
     };
@@ -702,6 +728,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
             if (kbase + (r & 3) + 8 * (r >> 2) >= p.Lk) s[r] = -1.0e30f;
     };
     auto row_max = [&](const f32x16_t& s) __attribute__((always_inline)) {
+        if (NOMAX) return TOP;
         const float mx = fw8_max16(s);
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         float r;
@@ -710,6 +737,18 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     };
     // 8 scores s[8g .. 8g+7] -> two e4m3 words; returns their fp32 sum (used by the VALU_SUM arm only)
     auto exp_pack8 = [&](const f32x16_t& s, int g, int& w0, int& w1) __attribute__((always_inline)) {
+        if (NOCVT) { w0 = __float_as_int(s[8 * g]); w1 = __float_as_int(s[8 * g + 4]); return 0.f; }
+        if (LIN) {                              // the byte is the rounded score (the `old` operand of a word's first conversion is dead)
+            unsigned x = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g], 0, __float_as_uint(s[8 * g]));
+            x = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 1], 1, x);
+            x = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 2], 2, x);
+            w0 = (int)__builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 3], 3, x);
+            unsigned y = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 4], 0, __float_as_uint(s[8 * g + 4]));
+            y = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 5], 1, y);
+            y = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 6], 2, y);
+            w1 = (int)__builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 7], 3, y);
+            return 0.f;
+        }
         const float a0 = __builtin_amdgcn_exp2f(s[8 * g]), a1 = __builtin_amdgcn_exp2f(s[8 * g + 1]);
         const float a2 = __builtin_amdgcn_exp2f(s[8 * g + 2]), a3 = __builtin_amdgcn_exp2f(s[8 * g + 3]);
         const float a4 = __builtin_amdgcn_exp2f(s[8 * g + 4]), a5 = __builtin_amdgcn_exp2f(s[8 * g + 5]);
@@ -723,10 +762,12 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     };
     // everything accumulated so far shrinks by 2^-delta
     auto shrink = [&](float delta) __attribute__((always_inline)) {
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        const float alpha = __builtin_amdgcn_exp2f(-delta * (1.0f / UNIT));
         l_run *= alpha;
+        if (!V2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+            for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+        }
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -737,16 +778,27 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     auto rescale = [&](float delta) __attribute__((always_inline)) {
         shrink(delta);
         M += delta;
-        set_negM();
+        if (V2) {
+            // -(M + delta) = (-M) - delta, the same bits -- but written as an update of every register BY ITSELF: the splat
+            // `negM[r] = -M` makes the new tuple sixteen copies of one value, which the register coalescer cannot merge with the old tuple,
+            // and it paid for that with eight v_mov_b64 on the COMMON path of every tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negM[r] -= delta;
+        } else {
+            set_negM();
+        }
     };
 
     // own fragment reads done, own requests done except the four newest (K(t+4), K(t+5), Vt(t+2), Vt(t+3) at a barrier of tile t:
     // K <= t+3 and Vt <= t+1 have landed), then the work-group barrier that publishes everybody's
-    auto sync = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        fw8_wait_vm<4>();
+    auto sync = [&](auto pair_tag) __attribute__((always_inline)) {
+        // (V2: no lgkmcnt(0) here.  The barrier orders the tile REQUESTS against the reads of the slot they overwrite, and that slot was
+        //  last read five tiles -- five barriers -- ago (K(t+5) lands in the slot of K(t-3), Vt(t+3) in that of Vt(t-5)); a wave's own
+        //  fragment reads of the current tile need not have returned.  The wait exposed a full LDS latency per tile behind the Vt reads.)
+        if (!V2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!NOREQ) { if (decltype(pair_tag)::value) fw8_wait_vm<2>(); else fw8_wait_vm<4>(); }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
+        if (!NOBAR) asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -760,8 +812,8 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         const int sl = SLT >= 0 ? SLT : (t & (RING_SP - 1));
         const int sl1 = SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : ((t + 1) & (RING_SP - 1));
         const int sl2 = SLT >= 0 ? ((SLT + 2) & (RING_SP - 1)) : ((t + 2) & (RING_SP - 1));
-        if (__builtin_expect(__any(mx0 > 8.0f), 0)) {   // block 0 would overflow e4m3: move the shift so that the largest P is 2^7 again
-            const float delta = fmaxf(mx0 - 7.0f, 0.f);
+        if (__builtin_expect(__any(mx0 > OVF), 0)) {    // block 0 would overflow e4m3: move the shift so that the largest P is 2^7 again
+            const float delta = fmaxf(mx0 - TOP, 0.f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) S0[r] -= delta;
             rescale(delta);
@@ -786,12 +838,12 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         S1 = FW8_MFMA(fr[0], qf[0], negM, qs);
         FW8_FENCE();
         ls += exp_pack8(S0, 0, pw[0], pw[1]);
-        fr[0] = frag32(vbase + vco[0], vbase + vco[1]);
+        if (!NOLDS) fr[0] = frag32(vbase + vco[0], vbase + vco[1]);
         FW8_FENCE();
         S1 = FW8_MFMA(fr[1], qf[1], S1, qs);
         FW8_FENCE();
         ls += exp_pack8(S0, 1, pw[2], pw[3]);
-        fr[1] = frag32(vbase + 32 * 64 + vco[0], vbase + 32 * 64 + vco[1]);
+        if (!NOLDS) fr[1] = frag32(vbase + 32 * 64 + vco[0], vbase + 32 * 64 + vco[1]);
         // block 0's probabilities are FINAL here in the common case: keep them on this side of the branch below (the compiler
         // otherwise sinks the exponentials behind it, and the row maximum then waits for the MFMAs with nothing to do)
         asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]));
@@ -799,8 +851,8 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         if (MASK) mask_block(S1, t, 1);
         {
             const float mx1 = row_max(S1);
-            if (__builtin_expect(__any(mx1 > 8.0f), 0)) {      // rare: block 1 would overflow e4m3 under the tile's shift -- redo block 0
-                const float delta = fmaxf(mx1 - 7.0f, 0.f);
+            if (__builtin_expect(__any(mx1 > OVF), 0)) {       // rare: block 1 would overflow e4m3 under the tile's shift -- redo block 0
+                const float delta = fmaxf(mx1 - TOP, 0.f);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
                 rescale(delta);
@@ -813,18 +865,18 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         if (NEXT) S0 = FW8_MFMA(fr[2], qf[0], negM, qs);
         FW8_FENCE();
         ls += exp_pack8(S1, 0, pw[4], pw[5]);
-        fr[2] = frag32(vbase + 2 * 32 * 64 + vco[0], vbase + 2 * 32 * 64 + vco[1]);
+        if (!NOLDS) fr[2] = frag32(vbase + 2 * 32 * 64 + vco[0], vbase + 2 * 32 * 64 + vco[1]);
         FW8_FENCE();
         if (NEXT) S0 = FW8_MFMA(fr[3], qf[1], S0, qs);
         FW8_FENCE();
         ls += exp_pack8(S1, 1, pw[6], pw[7]);
-        fr[3] = frag32(vbase + 3 * 32 * 64 + vco[0], vbase + 3 * 32 * 64 + vco[1]);
+        if (!NOLDS) fr[3] = frag32(vbase + 3 * 32 * 64 + vco[0], vbase + 3 * 32 * 64 + vco[1]);
         if (VALU_SUM) l_run += ls;
         FW8_FENCE();
-        if (NEXT && late) sync();               // waves 4-7: this tile's barrier (they run stage B beside the others' next stage A)
+        if (NEXT && late) sync(std::false_type{});               // waves 4-7: this tile's barrier (they run stage B beside the others' next stage A)
         const i32x8_t pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
         // ---- B: O^T += Vt(t) P(t)^T (+ the row sums)  ||  K1(t+1), K0(t+2) fragments; ragged mask and row maximum of block 0 of S(t+1)
-        if (!VALU_SUM) {
+        if (!VALU_SUM && !NOSUM) {
             // A operand = 1.0 in every e4m3 byte, written into registers the exponentials have just released (8 v_mov per tile
             // against the 32 adds they replace): a resident block would not fit beside the accumulators
             const i32x8_t ones = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};
@@ -832,21 +884,148 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
             FW8_FENCE();
         }
         o[0] = FW8_MFMA(fr[0], pf, o[0], 0x7f7f7f7f);
-        if (NEXT) fr[0] = k_frag(sl1, 1, 0);
+        if (NEXT && !NOLDS) fr[0] = k_frag(sl1, 1, 0);
         FW8_FENCE();
         o[1] = FW8_MFMA(fr[1], pf, o[1], 0x7f7f7f7f);
-        if (NEXT) fr[1] = k_frag(sl1, 1, 1);
+        if (NEXT && !NOLDS) fr[1] = k_frag(sl1, 1, 1);
         FW8_FENCE();
         o[2] = FW8_MFMA(fr[2], pf, o[2], 0x7f7f7f7f);
-        if (NEXT2) fr[2] = k_frag(sl2, 0, 0);
+        if (NEXT2 && !NOLDS) fr[2] = k_frag(sl2, 0, 0);
         FW8_FENCE();
         o[3] = FW8_MFMA(fr[3], pf, o[3], 0x7f7f7f7f);
-        if (NEXT2) fr[3] = k_frag(sl2, 0, 1);
+        if (NEXT2 && !NOLDS) fr[3] = k_frag(sl2, 0, 1);
 #undef FW8_FENCE
         if (NEXT) {
             if (MASKN) mask_block(S0, t + 1, 0);
             mx0 = row_max(S0);
-            if (!late) sync();                   // waves 0-3 (all eight when not skewed): this tile's barrier
+            if (!late) sync(std::false_type{});                   // waves 0-3 (all eight when not skewed): this tile's barrier
+        }
+    };
+    // ROUND 6 (VAR bit 9): the same tile with TWO basic blocks instead of five.  What the compiler made of the body above (ISA of round
+    // 5, tests/test_abi.py prints it): the `if (late) sync()` in the middle and the two overflow branches cut it into blocks, block 1's
+    // conversions sank behind the loop latch, Vt d-blocks 2, 3 were read BEFORE the two S0(t+1) MFMAs with an s_waitcnt lgkmcnt(0) between
+    // them (a full LDS latency exposed per tile and wave), and the five PV MFMAs issued back to back with nothing beside them.  Here
+    //   * `late` is a template argument of the tile (the two halves of the work-group run two copies of the loop): no branch around the
+    //     barrier;
+    //   * ONE overflow test per tile, after S1: block 0's probabilities are converted beside the S1 MFMAs on the assumption that the shift
+    //     holds (it does on all but a handful of tiles), and the rare repair redoes them -- S0 is intact until the first S0(t+1) MFMA;
+    //     (Tried: the shift splatted from one register into each score block before its first MFMA instead of a resident 16-register
+    //     tuple that the compiler copies every tile: 16 v_mov_b32 + 8 v_mov_b64 per block.  And: the repair OUTSIDE the steady loop -- leave after block 1, repair, finish the tile, enter again -- so that the shift's 16
+    //     registers are loop-invariant and the compiler stops copying them every tile: it merged the paths back and spilled 31 registers.)
+    //   * the row sums go through a temporary accumulator into one register (below).
+    // block 1 of tile t; returns the tile's largest score under the current shift (> OVF: the caller repairs before block 2)
+    // block 1 of tile t; returns the tile's largest score under the current shift (> OVF: the caller repairs before block 2)
+    // the shift as the accumulator input of a score block's first MFMA: splatted from ONE register into the block's own (dead) registers
+    // each time -- 8 v_mov_b64, what the compiler spent per tile on COPYING a resident 16-register shift (it made the in-loop repair a
+    // phi of the whole tuple), without the 32 registers the resident copy and its copy cost (Q was spilled to pay for them)
+    auto shift16 = [&]() __attribute__((always_inline)) {
+        const float v = -M;
+        return f32x16_t{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
+    };
+    auto tile2_a = [&](int t, auto next_tag, auto mask_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(next_tag)::value, MASK = decltype(mask_tag)::value;
+        constexpr int SLT = decltype(slot_tag)::value;         // the tile's ring slot when known at compile time, else -1
+        const char* vbase = smem + (SLT >= 0 ? SLT : (t & (RING_SP - 1))) * V8_TILE;
+#define FW8_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // ---- block 1: requests; S1(t) (2 MFMAs)  ||  P of block 0, Vt d-blocks 0, 1; row maximum of S1, the tile's overflow test
+        FW8_FENCE();
+        if (NEXT && !REQ_PV) {
+            issue_k(min(t + 5, nt - 1), t + 5);
+            issue_v(min(t + 3, nt - 1), t + 3);
+        }
+        FW8_FENCE();
+        S1 = FW8_MFMA(fr[0], qf[0], negM, qs);
+        FW8_FENCE();
+        exp_pack8(S0, 0, pw[0], pw[1]);
+        FW8_FENCE();
+        S1 = FW8_MFMA(fr[1], qf[1], S1, qs);
+        FW8_FENCE();
+        exp_pack8(S0, 1, pw[2], pw[3]);
+        if (!NOLDS) {
+            fr[0] = frag32(vbase + vco[0], vbase + vco[1]);
+            fr[1] = frag32(vbase + 32 * 64 + vco[0], vbase + 32 * 64 + vco[1]);
+        }
+        // block 0's probabilities stay on this side of the overflow branch (the compiler otherwise sinks the conversions behind it, out
+        // of the S1 MFMAs' shadow)
+        asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]));
+        FW8_FENCE();
+        if (MASK) mask_block(S1, t, 1);
+        float mx;
+        { const float m1 = row_max(S1); asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx0), "v"(m1)); }
+        return mx;
+    };
+    // rare: a score of this tile would overflow e4m3 under the shift -- move it, redo block 0's probabilities (S0 is intact until block 2)
+    auto tile2_repair = [&](float mx) __attribute__((always_inline)) {
+        const float delta = fmaxf(mx - TOP, 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
+        rescale(delta);
+        exp_pack8(S0, 0, pw[0], pw[1]);
+        exp_pack8(S0, 1, pw[2], pw[3]);
+    };
+    // sync_tag: 1 = the tile's barrier (the four newest requests may be in flight), 2 = the barrier of a PAIR of tiles (BAR2: only the
+    // two newest -- K <= t+4 and Vt <= t+2 must be visible for the two tiles that follow), 0 = none (the first tile of a pair)
+    auto tile2_b = [&](int t, auto late_tag, auto next_tag, auto next2_tag, auto maskn_tag, auto sync_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr bool LATE = decltype(late_tag)::value;
+        constexpr int SYNC = decltype(sync_tag)::value;
+        constexpr int SLT = decltype(slot_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value, MASKN = decltype(maskn_tag)::value;
+        const int sl = SLT >= 0 ? SLT : (t & (RING_SP - 1)), sl1 = SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : ((t + 1) & (RING_SP - 1));
+        const int sl2 = SLT >= 0 ? ((SLT + 2) & (RING_SP - 1)) : ((t + 2) & (RING_SP - 1));
+        const char* vbase = smem + sl * V8_TILE;
+        // ---- block 2: S0(t+1) (2 MFMAs)  ||  P of block 1, Vt d-blocks 2, 3;  [late waves: barrier];  row sums + PV (5 MFMAs)  ||
+        //      K1(t+1), K0(t+2) fragments, row maximum of S0(t+1);  [early waves: barrier]
+        FW8_FENCE();
+        if (NEXT) S0 = FW8_MFMA(fr[2], qf[0], negM, qs);
+        FW8_FENCE();
+        exp_pack8(S1, 0, pw[4], pw[5]);
+        FW8_FENCE();
+        if (NEXT) S0 = FW8_MFMA(fr[3], qf[1], S0, qs);
+        FW8_FENCE();
+        exp_pack8(S1, 1, pw[6], pw[7]);
+        if (!NOLDS) {
+            fr[2] = frag32(vbase + 2 * 32 * 64 + vco[0], vbase + 2 * 32 * 64 + vco[1]);
+            fr[3] = frag32(vbase + 3 * 32 * 64 + vco[0], vbase + 3 * 32 * 64 + vco[1]);
+        }
+        FW8_FENCE();
+        if (NEXT && LATE && SYNC) sync(std::integral_constant<bool, SYNC == 2>{});
+        const i32x8_t pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+        // the tile's row sums: ones x P on the matrix pipe into the registers S1 has just released (C = 0), added to ONE register after the
+        // PV MFMAs -- a resident 16-register accumulator whose registers all hold the same number does not fit beside the rest
+        f32x16_t tsum;
+        if (!NOSUM) {
+            // A = 1.0 in every e2m1 nibble (cbsz 4: the A operand is fp4, four registers instead of eight; B stays e4m3)
+            // (the builtin takes eight; instruction selection keeps the four an fp4 operand has)
+            const i32x8_t ones = {0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222};
+            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            tsum = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf, zero, 4, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            FW8_FENCE();
+        }
+        o[0] = FW8_MFMA(fr[0], pf, o[0], 0x7f7f7f7f);
+        if (NEXT && !NOLDS) fr[0] = k_frag(sl1, 1, 0);
+        // REQ_PV: K(t+5) / Vt(t+3) requested HERE, with four PV MFMAs queued behind -- an LDS-DMA request costs the wave 60-185 cycles of
+        // issue (MI355X_MICROARCH.md), which at the top of the tile nothing covers (all eight waves are there together, behind the
+        // barrier, with the matrix pipe drained).  Same slots, same count at the barrier: the four newest requests still are
+        // K(t+4), K(t+5), Vt(t+2), Vt(t+3).
+        if (NEXT && REQ_PV) issue_k(min(t + 5, nt - 1), SLT >= 0 ? SLT + 5 : t + 5);
+        FW8_FENCE();
+        o[1] = FW8_MFMA(fr[1], pf, o[1], 0x7f7f7f7f);
+        if (NEXT && !NOLDS) fr[1] = k_frag(sl1, 1, 1);
+        if (NEXT && REQ_PV) issue_v(min(t + 3, nt - 1), SLT >= 0 ? SLT + 3 : t + 3);
+        FW8_FENCE();
+        o[2] = FW8_MFMA(fr[2], pf, o[2], 0x7f7f7f7f);
+        if (NEXT2 && !NOLDS) fr[2] = k_frag(sl2, 0, 0);
+        FW8_FENCE();
+        o[3] = FW8_MFMA(fr[3], pf, o[3], 0x7f7f7f7f);
+        if (NEXT2 && !NOLDS) fr[3] = k_frag(sl2, 0, 1);
+        FW8_FENCE();
+        if (!NOSUM) l_run += tsum[0];
+        FW8_FENCE();
+#undef FW8_FENCE
+        if (NEXT) {
+            if (MASKN) mask_block(S0, t + 1, 0);
+            mx0 = row_max(S0);
+            if (!LATE && SYNC) sync(std::integral_constant<bool, SYNC == 2>{});
         }
     };
     using T_ = std::true_type;
@@ -871,14 +1050,63 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     S1 = FW8_MFMA(fr[0], qf[0], negM, qs);
     S1 = FW8_MFMA(fr[1], qf[1], S1, qs);
     if (ragged && nt == 1) { mask_block(S0, 0, 0); mask_block(S1, 0, 1); }
-    M = fmaxf(row_max(S0), row_max(S1)) - 7.0f;   // the first tile's largest P is 2^7 (tile 0 recomputes S1 under this shift)
+    M = fmaxf(row_max(S0), row_max(S1)) - TOP;    // the first tile's largest P is 2^7 (tile 0 recomputes S1 under this shift)
     set_negM();
 #pragma unroll
     for (int r = 0; r < 16; ++r) S0[r] -= M;
-    mx0 = 7.0f;
+    mx0 = TOP;
     if (nt > 1) { fr[2] = k_frag(1, 0, 0); fr[3] = k_frag(1, 0, 1); }
 
     // ---- tiles 0 .. nt-1; the steady bodies are unrolled by the ring depth so that ring slots are immediates of the ds_reads
+    if (V2) {
+        auto run = [&](auto late_tag) __attribute__((always_inline)) {
+            using S1_ = std::integral_constant<int, 1>;
+            // a pair of steady tiles, one barrier (BAR2)
+            auto pair = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+                constexpr int SLT = decltype(slot_tag)::value;
+                using NXT = std::integral_constant<int, (SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : -1)>;
+                float mx = tile2_a(t, T_{}, F_{}, slot_tag);
+                if (__builtin_expect(__any(mx > OVF), 0)) tile2_repair(mx);
+                tile2_b(t, late_tag, T_{}, T_{}, F_{}, std::integral_constant<int, 0>{}, slot_tag);
+                mx = tile2_a(t + 1, T_{}, F_{}, NXT{});
+                if (__builtin_expect(__any(mx > OVF), 0)) tile2_repair(mx);
+                tile2_b(t + 1, late_tag, T_{}, T_{}, F_{}, std::integral_constant<int, 2>{}, NXT{});
+            };
+            int t = 0;
+            if (BAR2 && UNR8) {
+#pragma unroll 1
+                for (; t + 9 < nt; t += 8) {          // eight steady tiles: t is a multiple of the ring depth, the slots are immediates
+                    pair(t, std::integral_constant<int, 0>{});
+                    pair(t + 2, std::integral_constant<int, 2>{});
+                    pair(t + 4, std::integral_constant<int, 4>{});
+                    pair(t + 6, std::integral_constant<int, 6>{});
+                }
+            }
+            if (BAR2) {
+#pragma unroll 1
+                for (; t + 3 < nt; t += 2) pair(t, SR{});      // pairs of steady tiles, one barrier per pair
+            }
+#pragma unroll 1
+            for (; t + 2 < nt; ++t) {                 // steady tiles (two successors)
+                const float mx = tile2_a(t, T_{}, F_{}, SR{});
+                if (__builtin_expect(__any(mx > OVF), 0)) tile2_repair(mx);
+                tile2_b(t, late_tag, T_{}, T_{}, F_{}, S1_{}, SR{});
+            }
+            if (t + 1 < nt) {                         // second-last tile
+                const float mx = tile2_a(t, T_{}, F_{}, SR{});
+                if (__builtin_expect(__any(mx > OVF), 0)) tile2_repair(mx);
+                if (ragged) tile2_b(t, late_tag, T_{}, F_{}, T_{}, S1_{}, SR{}); else tile2_b(t, late_tag, T_{}, F_{}, F_{}, S1_{}, SR{});
+                ++t;
+            }
+            {                                         // last tile
+                const float mx = ragged ? tile2_a(t, F_{}, T_{}, SR{}) : tile2_a(t, F_{}, F_{}, SR{});
+                if (__builtin_expect(__any(mx > OVF), 0)) tile2_repair(mx);
+                tile2_b(t, late_tag, F_{}, F_{}, F_{}, S1_{}, SR{});
+            }
+        };
+        static_assert(!V2 || !SKEW, "the two-block tile runs all eight waves in phase");
+        run(F_{});
+    } else {
     int t = 0;
 #pragma unroll 1
     for (; t + 2 < nt; ++t) tile(t, SR{}, T_{}, T_{}, F_{}, F_{});       // steady tiles (two successors)
@@ -887,11 +1115,19 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         ++t;
     }
     if (ragged) tile(t, SR{}, F_{}, F_{}, T_{}, F_{}); else tile(t, SR{}, F_{}, F_{}, F_{}, F_{});       // last tile
+    }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l
     float l_tot;
     if (VALU_SUM) l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    else l_tot = osum[0];                          // every accumulator register of the ones-MFMA holds this lane's query's row sum
+    else if (V2) l_tot = NOSUM ? 1.0f : l_run;
+    else l_tot = NOSUM ? 1.0f : osum[0];           // every accumulator register of the ones-MFMA holds this lane's query's row sum
+    if (V2) {
+        // the accumulators are FINAL before the only divergent branch of the kernel: without this the compiler sinks the last tile's
+        // MFMAs into the rows-below-Lq guard (MFMAs under a partial EXEC; the in-phase instantiation returned garbage for every wave that
+        // holds rows past Lq)
+        asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(l_tot));
+    }
     const float inv = 1.0f / l_tot;
     if (q_row < p.Lq) {
         uint16_t* dst = Op + (int64_t)q_row * p.ldo;
@@ -949,19 +1185,36 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
     p.q_scale_e8m0 = e | (e << 8) | (e << 16) | (e << 24);
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_fp8: grid too large"); return FW_E_BADARG; }
-    // default (round 5): the single-stream kernel with the row sums on the matrix pipe.  A/B arms by FW_ATTN_VAR: 8 = the in-phase
-    // kernel, 9 = the two-group ping-pong kernel (the round-2..4 default), 10 = single-stream with fp32 row sums on the vector pipe,
-    // 11 = single-stream with all eight waves in phase (no half-tile skew between the two waves of a SIMD).
+    // default (round 6): the single-stream kernel, linear-byte probabilities, two-block tile, requests between the PV MFMAs, one barrier
+    // per two tiles, steady loop unrolled by the ring depth.  A/B arms by FW_ATTN_VAR (tools/attn_fp8_ab.py) -- the steps that led there:
+    //   8 / 9    the in-phase kernel of round 2 / the two-group ping-pong kernel (rounds 2-4)
+    //   12 / 13  round 5's kernel: exact exponential (v_exp_f32 + v_cvt_pk_fp8_f32), half-tile skew / all eight waves in phase
+    //   14       + linear-byte probabilities (one v_cvt_pk_u8_f32 per score), round 5's tile body
+    //   11       + the tile body in two basic blocks, in phase, row sums through a temporary accumulator   (bit-identical from here on)
+    //   15       + tile requests between the PV MFMAs
+    //   16       + one barrier per two tiles
     // Views of 4 GiB or more do not fit the descriptors' 32-bit byte offsets: they keep the ping-pong kernel (pointer requests).
     const int var = fw_get_option(FW_OPT_ATTN_VAR);
     const bool big = (uint64_t)Lk * (uint64_t)ldk >= 0xffffffffull || (uint64_t)head_dim * (uint64_t)lkp >= 0xffffffffull ||
                      (uint64_t)(Lk + 6 * KVB) * (uint64_t)ldk >= 0x7fffffffull;
-    if (var == 8) hipLaunchKernelGGL(attention_fp8_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
-    else if (var == 9 || big) hipLaunchKernelGGL(attention_fp8_pp_kernel, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+#define FW8_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p)
+    if (var == 8) FW8_LAUNCH(attention_fp8_kernel);
+    else if (var == 9 || big) FW8_LAUNCH(attention_fp8_pp_kernel);
     // (FW_ATTN_VAR=10, the in-phase arm with fp32 row sums on the vector pipe, is gone since round 6: it was the slower arm, and under
     //  -fno-associative-math its error at 64+ tiles grew from 5.4e-2 to 7.0e-2 against the fp32 softmax while every other arm kept its
     //  round-5 bits -- not worth a fourth instantiation with 440 B of scratch; 10 now selects the default kernel)
-    else if (var == 11) hipLaunchKernelGGL((attention_fp8_sp_kernel<2>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attention_fp8_sp_kernel<0>), dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p);
+    else if (var == 12) FW8_LAUNCH((attention_fp8_sp_kernel<0>));
+    else if (var == 13) FW8_LAUNCH((attention_fp8_sp_kernel<2>));
+    else if (var == 14) FW8_LAUNCH((attention_fp8_sp_kernel<4>));
+    else if (var == 11) FW8_LAUNCH((attention_fp8_sp_kernel<512 + 6>));
+    else if (var == 15) FW8_LAUNCH((attention_fp8_sp_kernel<1024 + 512 + 6>));
+    else if (var == 16) FW8_LAUNCH((attention_fp8_sp_kernel<2048 + 1024 + 512 + 6>));
+#ifdef FW8_KNOCKOUTS                 // timing-only arms of a tagged build (tools/attn_fp8_knockout.py): FW_ATTN_VAR = 1000 + knock-out bits
+#define FW8_KO(bits) else if (var == 1000 + (bits)) FW8_LAUNCH((attention_fp8_sp_kernel<16384 + 2048 + 1024 + 512 + 6 + (bits)>));
+    FW8_KO(8) FW8_KO(16) FW8_KO(32) FW8_KO(64) FW8_KO(256) FW8_KO(8 + 256) FW8_KO(16 + 32) FW8_KO(16 + 32 + 64) FW8_KO(8 + 16 + 32 + 64)
+#undef FW8_KO
+#endif
+    else FW8_LAUNCH((attention_fp8_sp_kernel<16384 + 2048 + 1024 + 512 + 6>));
+#undef FW8_LAUNCH
     return (int)hipGetLastError();
 }

@@ -427,6 +427,7 @@ class TorchRefOps:
     # statement of the semantics the header states, so that the host orchestration (what is cast when, what the exchanges carry, which
     # heads a rank attends to) can be exercised over gloo without a GPU.  e4m3 tensors travel as uint8 views, like on the HIP side.
     FP8_Q_EXP = 3
+    fp8_linear_exp = True         # the probabilities of attention_fp8: the piecewise-linear byte form (kernel default) or e4m3(exp2)
 
     def q_scale_fp8(self, hd):
         return self.q_scale(hd) * float(2 ** self.FP8_Q_EXP)
@@ -455,7 +456,12 @@ class TorchRefOps:
         vh = dec(vt8).reshape(batch, Lk, heads, hd).transpose(1, 2)
         s = qh.double() @ kh.double().transpose(-1, -2)                 # log2-domain scores; e4m3 products: exact in fp64
         m = s.amax(dim=-1, keepdim=True)
-        pr = torch.exp2((s - m + 7.0).float()).to(torch.float8_e4m3fn).to(torch.float64)     # P = e4m3(2^(s - m + 7))
+        if self.fp8_linear_exp:      # round 6 default of the kernel: the e4m3 BYTE of P is round(8 (s - m + 7) + 56) -- 2^f ~ 1 + f inside a
+            # binade, v_cvt_pk_u8_f32's round-to-nearest-even and saturation at 0 (csrc/attention_fp8.hip, tools/probes/cvt_pk_u8_probe.hip)
+            bits = torch.round(8.0 * (s - m).float() + 112.0).clamp(0, 255).to(torch.uint8)
+            pr = bits.view(torch.float8_e4m3fn).to(torch.float64)
+        else:                        # FW_ATTN_VAR=12: P = e4m3(2^(s - m + 7))
+            pr = torch.exp2((s - m + 7.0).float()).to(torch.float8_e4m3fn).to(torch.float64)
         o = ((pr @ vh.double()) / pr.sum(dim=-1, keepdim=True)).float()  # numerator and normaliser from the SAME rounded P
         o = self._r(o.transpose(1, 2).reshape(batch * Lq, heads * hd))
         if out is not None:

@@ -102,7 +102,7 @@ def test_hot_kernels_do_not_spill():
     if not os.path.exists(os.path.join(kernel_resources.LLVM, "llvm-readelf")):
         pytest.skip("ROCm LLVM tools not found")
     table = {name.replace("void ", ""): (vg, ag, lds, scr) for _, name, vg, ag, lds, scr in kernel_resources.all_kernels()}
-    must_be_clean = ["attention_sp_kernel<128, 65>", "attention_sp_kernel<128, 1>", "attention_sp_kernel<64, 1>", "attention_sp_kernel<96, 1>",
+    must_be_clean = ["attention_fp8_sp_kernel<518>", "attention_sp_kernel<128, 65>", "attention_sp_kernel<128, 1>", "attention_sp_kernel<64, 1>", "attention_sp_kernel<96, 1>",
                      "attention_pp3_kernel<96, 0>", "gemm_bf16_two_slot_kernel<0>", "gemm_bf16_four_slot_kernel<0, false>", "gemm_bf16_four_slot_kernel<0, true>",
                      "gemm_fp8_pp_kernel", "gemm_fp8_two_slot_kernel", "layernorm_lds_kernel<20, false, true>", "layernorm_lds_kernel<20, true, false>",
                      "layernorm_lds_kernel<4, true, true>", "qk_prep_wave_kernel<10, 1, 1, 0>", "qk_prep_wave_kernel<10, 1, 1, 1>",
@@ -165,22 +165,45 @@ class _Listing(list):
         return out
 
 
+FP8_DEFAULT = "attention_fp8_sp_kernel<19974>"          # 16384 unrolled by the ring + 2048 pair barrier + 1024 requests in PV + 512 two-block tile + 4 linear byte + 2 in phase
+
+
 def test_fp8_attention_steady_loop_has_no_scratch_traffic():
-    """attention_fp8_sp_kernel<0> (the fp8 default) carries scratch in its PEELED second-last / last tiles (608 B per
-    lane, ~200 scratch ops outside the loop), so `scratch == 0` cannot be asserted for it like for the bf16 kernels; what must hold is
-    that the STEADY loop -- every tile but two at production key counts -- has none: a spill that moves into the loop body is a 2-3x
-    regression nothing else would notice."""
-    kernels = {k: v for k, v in _disassemble("attention_fp8").items() if "attention_fp8_sp_kernel<0>" in k}
-    assert len(kernels) == 1, sorted(kernels)
+    """the fp8 default carries scratch in its PEELED tiles (round 5: 608 B per lane; round 6's two-block tile: 68 B),
+    so `scratch == 0` cannot be asserted for it like for the bf16 kernels; what must hold is that the STEADY loops -- every tile but a
+    handful at production key counts -- have none: a spill that moves into a loop body is a 2-3x regression nothing else would notice
+    (and scratch traffic shares vmcnt with the tile requests the barrier counts).  Round 6's default has three of them: eight tiles
+    unrolled by the ring depth (72 MFMAs), the pair loop (18) and the single-tile loop (9)."""
+    kernels = {k: v for k, v in _disassemble("attention_fp8").items() if FP8_DEFAULT in k}
+    assert len(kernels) == 1, sorted(k[:60] for k in _disassemble("attention_fp8"))
     (name, ins), = kernels.items()
-    # the steady tile loop: the tightest backward branch whose body holds a tile's 9 MFMAs (2 + 2 score, 1 row-sum, 4 PV) and its barrier
-    loops = [(a, b) for a, b in ins.loops(min_mfma=9) if any(t.startswith("s_barrier") for t in ins[a:b + 1])]
-    assert loops, "no steady tile loop found"
-    first, last = min(loops, key=lambda ab: ab[1] - ab[0])
-    body = ins[first:last + 1]
-    assert sum("mfma" in t for t in body) == 9 and last - first < 260, (first, last)
-    assert not [t for t in body if t.startswith("scratch_")], [t for t in body if t.startswith("scratch_")][:4]
+    found = {}
+    for want in (72, 18, 9):
+        # the tightest backward branch whose body holds exactly that many MFMAs (9 per tile: 2 + 2 score, 1 row-sum, 4 PV) and a barrier
+        loops = [(a, b) for a, b in ins.loops(min_mfma=want)
+                 if sum("mfma" in t for t in ins[a:b + 1]) == want and any(t.startswith("s_barrier") for t in ins[a:b + 1])]
+        assert loops, f"no steady loop with {want} MFMAs found"
+        first, last = min(loops, key=lambda ab: ab[1] - ab[0])
+        body = ins[first:last + 1]
+        assert last - first < 30 * want, (want, first, last)               # ~17 instructions per MFMA; a spill storm or a lost unroll shows here
+        assert not [t for t in body if t.startswith("scratch_")], (want, [t for t in body if t.startswith("scratch_")][:4])
+        found[want] = sum(t.startswith("v_") and "mfma" not in t for t in body) / (want // 9)
+    # the vector instructions per tile that the schedule was built around (round 5: 98; linear bytes 91; no shift copies 77; immediates 63)
+    assert found[72] <= 66 and found[18] <= 80, found
     assert any(t.startswith("scratch_") for t in ins), "the peeled tiles no longer spill: assert scratch == 0 in test_hot_kernels_do_not_spill instead"
+
+
+def test_fp8_attention_probabilities_are_integer_conversions():
+    """Round 6: the default's steady loop holds NO transcendental -- P's e4m3 byte is v_cvt_pk_u8_f32 of the score (csrc/attention_fp8.hip,
+    tools/probes/cvt_pk_u8_probe.hip): 32 conversions per tile; the exact-exponential A/B arm keeps 32 v_exp_f32 + 16 v_cvt_pk_fp8_f32."""
+    ks = _disassemble("attention_fp8")
+    for which, want in ((FP8_DEFAULT, ("v_cvt_pk_u8_f32", 32 * 8, "v_exp_f32", 0)), ("attention_fp8_sp_kernel<0>", ("v_exp_f32", 32, "v_cvt_pk_u8_f32", 0))):
+        (name, ins), = [(k, v) for k, v in ks.items() if which in k]
+        mf = 72 if which == FP8_DEFAULT else 9
+        loops = [(a, b) for a, b in ins.loops(min_mfma=mf) if sum("mfma" in t for t in ins[a:b + 1]) == mf and any(t.startswith("s_barrier") for t in ins[a:b + 1])]
+        first, last = min(loops, key=lambda ab: ab[1] - ab[0])
+        body = ins[first:last + 1]
+        assert sum(t.startswith(want[0]) for t in body) == want[1] and sum(t.startswith(want[2]) for t in body) == want[3], (which, want)
 
 
 def test_fp8_attention_row_maximum_reads_mfma_results_behind_a_compiler_visible_read():
@@ -190,7 +213,7 @@ def test_fp8_attention_row_maximum_reads_mfma_results_behind_a_compiler_visible_
     every attention_fp8_sp_kernel instantiation is checked -- each v_max3 group is preceded by a v_readfirstlane of a register the group
     reads, with no MFMA that writes that block in between (the compiler pads that read with the s_nop the hazard needs)."""
     kernels = {k: v for k, v in _disassemble("attention_fp8").items() if "attention_fp8_sp_kernel" in k}
-    assert len(kernels) >= 2, sorted(kernels)          # <0> (default, skewed) and <2> (in phase); the VALU-sum arm <1> was removed in round 6
+    assert len(kernels) >= 7, sorted(k[:60] for k in kernels)      # the default and its six A/B arms (csrc/attention_fp8.hip: fw_attention_fp8)
     groups = 0
     for name, ins in kernels.items():
         for i, text in enumerate(ins):

@@ -769,7 +769,7 @@ def _digest_cases(ops):
         "attention_sp_kernel<128,65>/H2_2100x2100": lambda: attn(2, 128, 2100, 2100, 11),
         "attention_pp3_kernel<96,0>/H3_1500x1565": lambda: attn(3, 96, 1500, 1565, 21),
         "attention_sp_kernel<64,64>/H4_1565x1565": lambda: attn(4, 64, 1565, 1565, 31),
-        "attention_fp8_sp_kernel<0>/H2_2100x2100": lambda: attn8(2, 2100, 2100, 41),
+        "attention_fp8_sp_kernel<default>/H2_2100x2100": lambda: attn8(2, 2100, 2100, 41),
         "gemm_bf16_two_slot_kernel/2304x1536x1024_bias_gelu_bf16": lambda: gemm(2304, 1536, 1024, 51, act="gelu_tanh"),
         "gemm_bf16_two_slot_kernel/2304x1024x2048_gate_f32_residual": lambda: gemm(2304, 1024, 2048, 61, residual=True),
         "gemm_fp8_pp_kernel/2304x1024x1024_bias_bf16": lambda: gemm(2304, 1024, 1024, 71, fp8=True),

@@ -71,10 +71,15 @@ k96s = (k96.float() * ops.q_scale(96)).to(torch.bfloat16); q96r = mk(L, 12 * 96)
 q64 = (mk(L2, 16 * 64).float() * ops.q_scale(64)).to(torch.bfloat16); k64 = mk(L2, 16 * 64); v64 = mk(L2, 16 * 64)
 q8 = ops.cast_fp8((q.float() * ops.q_scale_fp8(128)).to(torch.bfloat16)); k8 = ops.cast_fp8(k)
 vt8, lk8 = ops.prepare_v_fp8(v, 8, 128)
-for rep in range(2):
+FP8_ONLY = [int(x) for x in os.environ.get("FP8_VARS", "").split(",") if x]      # FP8_VARS=192,12: only the fp8 kernel, these FW_ATTN_VAR arms
+for rep in range(2 if not FP8_ONLY else 0):
     for _ in range(3): ops.attention(qs, k, v, 8, 128, q_prescaled=True)
     for _ in range(3): ops.attention(q96, k96, v96, 12, 96, q_prescaled=True)
     for _ in range(3): ops.attention(k96s, q96r, q96r, 12, 96, q_prescaled=True)
     for _ in range(3): ops.attention(q64, k64, v64, 16, 64, q_prescaled=True)
     for _ in range(3): ops.attention_fp8(q8, k8, vt8, 8, 128, lk8)
+for var in FP8_ONLY:
+    ops.set_option("attn_var", var)
+    for _ in range(6): ops.attention_fp8(q8, k8, vt8, 8, 128, lk8)
+ops.set_option("attn_var", 192)
 torch.cuda.synchronize()

@@ -1,8 +1,15 @@
 #!/usr/bin/env python
-"""Interleaved A/B of the fp8 attention kernels (fw_attention_fp8, hd 128) in ONE process, random data, medians:
+"""Interleaved A/B of the fp8 attention kernels (fw_attention_fp8, hd 128) in ONE process, random data, medians -- the steps from
+round 4's kernel to round 6's default, each arm adding one thing (csrc/attention_fp8.hip lists them at fw_attention_fp8):
     FW_ATTN_VAR 9   two-group ping-pong kernel (rounds 2-4 default)
-    FW_ATTN_VAR 11  single-stream kernel (row sums by a ones-MFMA), all eight waves in phase
-    default         the same with the two waves of a SIMD half a tile apart (round 5 default)
+    13 / 12         round 5: single-stream kernel, row sums by a ones-MFMA, P = e4m3(exp2(.)) by v_exp_f32 + v_cvt_pk_fp8_f32; all eight waves
+                    in phase / the two waves of a SIMD half a tile apart (round 5's default)
+    14              + P's e4m3 byte = round(8 log2 P + 56) by ONE v_cvt_pk_u8_f32 per score (no transcendental in the loop)
+    11              + the tile body in two basic blocks (one overflow test, no branch around the barrier, in phase), row sums through a
+                    temporary accumulator, the shift updated register by register (no per-tile copies)
+    15              + the tile requests between the PV MFMAs
+    16              + one barrier per two tiles
+    default         + the steady loop unrolled by the ring depth (slot offsets are immediates)
 and the bf16 kernel on the same shape as the yardstick.  Shapes: the DiT self-attention of BASELINE configs[1] (L = 32 760) and
 configs[4] (L = 111 600), 8 of the 40 heads (same work per work-group).  -> stdout (tools/gpu_pass.sh run: stage logs it)."""
 import os, statistics, sys
@@ -33,7 +40,9 @@ for L in (32760, 111600):
     vt8, lk = ops.prepare_v_fp8(v, H, hd)
     qs = (q.float() * ops.q_scale(hd)).to(torch.bfloat16)
     vt = ops.prepare_v(v, H, hd)
-    arms = {"fp8 ping-pong (var 9)": 9, "fp8 single-stream, in phase (var 11)": 11, "fp8 single-stream, half-tile skew (default)": 192}
+    arms = {"9  ping-pong (rounds 2-4)": 9, "13 round 5, in phase": 13, "12 round 5, half-tile skew (its default)": 12,
+            "14 + linear-byte probabilities": 14, "11 + two-block tile, in phase": 11, "15 + requests between the PV MFMAs": 15,
+            "16 + one barrier per two tiles": 16, "default: + unrolled by the ring depth": 192}
     for extra in os.environ.get("EXTRA_VARS", "").split(","):
         if extra:
             arms[f"fp8 experiment var {extra}"] = int(extra)
@@ -54,5 +63,5 @@ for L in (32760, 111600):
     for name, ts in times.items():
         ms = statistics.median(ts)
         rel = "" if name == "bf16 kernel" else f"   rel-L2 vs bf16 kernel {((outs[name] - ref).norm() / ref.norm()).item():.3e}"
-        print(f"  {name:42s} {ms:9.3f} ms  {fl / ms / 1e9:8.1f} TF/s  ({fl / ms / 1e9 / 5000:.3f} of the 5 PF fp8 peak, {fl / ms / 1e9 / 2500:.3f} of 2.5 PF){rel}")
+        print(f"  {name:48s} {ms:9.3f} ms  {fl / ms / 1e9:8.1f} TF/s  ({fl / ms / 1e9 / 5000:.3f} of the 5 PF fp8 peak, {fl / ms / 1e9 / 2500:.3f} of 2.5 PF){rel}")
 ops.set_option("attn_var", 192)
