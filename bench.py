@@ -152,7 +152,10 @@ def attention_measured(hd):
             with open(os.path.join(ROOT, "profiles", rnd, "attn_counters.json")) as f:
                 rec = json.load(f)["hd%d" % hd]
             busy, ghz = float(rec["mfma_busy"]), float(rec["sustained_ghz"])
-            return {"mfma_busy": busy, "sustained_ghz": ghz, "predicted_frac_of_2p5_pf": round(busy * ghz / 2.4, 3),
+            # (round 6: the attention kernels sum their rows on the matrix pipe -- those MFMAs are busy cycles, not algorithmic work)
+            share = float(rec.get("algorithmic_share_of_mfma_cycles", 1.0))
+            return {"mfma_busy": busy, "sustained_ghz": ghz, "algorithmic_share_of_mfma_cycles": share,
+                    "predicted_frac_of_2p5_pf": round(busy * share * ghz / 2.4, 3),
                     "source": "stored PMC pass (not measured in this process): profiles/%s/%s" % (rnd, rec.get("file", "attn_counters.json"))}
         except (OSError, KeyError, ValueError):
             continue
@@ -509,7 +512,7 @@ def main():
                    "cfg_merged_in_one_pass": bool(args.merge_cfg and world == 1),
                    "tflop_per_step": step_flops / 1e12, "engine_build_s": round(t_build, 1)},
         "mfma_frac_whole_step": step_flops * value / (world * MFMA_BF16_PEAK),
-        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_sp_kernel<19974>" if fp8_attn else "attention_sp_kernel<128, 65>") + " (DiT self-attention, one launch per block"
+        "roofline": {"bound": "mfma", "kernel": ("attention_fp8_sp_kernel<52742>" if fp8_attn else "attention_sp_kernel<128, 577>") + " (DiT self-attention, one launch per block"
                                + ("" if n_groups == 1 else f", in {n_groups} head groups under the sequence shard")
                                + ("" if topo.tp is None else f", {cfg.num_heads // sp} of {cfg.num_heads} heads per tensor-parallel rank") + ")",
                      # peak / frac follow the DOMINANT KERNEL's arithmetic type: the e4m3 attention kernel is priced against the dense

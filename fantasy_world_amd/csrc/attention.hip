@@ -709,6 +709,7 @@ static __device__ __forceinline__ void fw_mfma_drain() {
 // 64-key tile (4-deep K / Vt LDS rings, K(t+3) and Vt(t+2) requested in iteration t, vmcnt(4) before the barrier).
 // Log2-domain scores (FW_ATTN_Q_PRESCALED), running max folded into the accumulator input, overflow check per half tile.
 // ---------------------------------------------------------------------------------------------------------------
+#define NS_OF(V) (((V) & 2) ? 2 : 1)
 template <int HD, int VAR>
 __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void attention_sp_kernel(AttnArgs p) {
     constexpr bool PINNED = (VAR & 1) != 0;   // sched_group_barrier pins on the stage bodies
@@ -722,6 +723,17 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     // tile (hd 128) on LDS addresses (16 v_add_u32, 9 v_or_b32, 2 v_lshl_add) -- and VALU cycles ADD to the matrix cycles on this
     // SIMD (docs/kernels.md, "attention: the cap").
     constexpr bool UNR = (VAR & 64) != 0;
+    // Round 6 (VAR bit 9): the row sums on the MATRIX pipe.  The 32 v_add_f32 per tile and wave were a third of the loop's vector
+    // instructions, and on this SIMD vector issue ADDS to matrix time (docs/kernels.md); a v_mfma_f32_16x16x32_bf16 (4 passes) whose A
+    // operand is a per-lane pattern of ones sums one 4-register chunk of P^T -- the operand the PV MFMAs read anyway -- into a 4-register
+    // accumulator that lives through the loop: 4 short MFMAs (64 matrix cycles) per tile instead of 32 vector adds.  The sums then are
+    // those of the bf16-ROUNDED probabilities, i.e. of exactly what the numerator multiplies (the fp32 sums of the unrounded p they
+    // replace differ from them by the rounding noise of P, which now cancels between numerator and denominator).  The A pattern: in
+    // the 16x16x32 shape lane l supplies B column l & 15, k-block l >> 4, so the P of query fi = l & 31 (lanes fi and fi + 32) sits in
+    // column fi & 15 on the k-blocks of parity fi >> 4, next to query fi ^ 16 on the others; output rows 4 (l >> 4) .. + 3 are the ones
+    // lane l reads, so row r must sum the k-blocks of the parity of r >> 2 (tools/probes/mfma16_layout_probe.hip pins the lane -> row /
+    // column / k-block map of the 16x16 shapes).  The "sum beyond 2^96" test moves behind the loop (one total bounds every half sum).
+    constexpr bool MSUM = (VAR & 512) != 0 && NS_OF(VAR) == 1;
     constexpr bool BUF = UNR && (VAR & 256) == 0;   // tile requests by SGPR descriptor + scalar tile offset (below); bit 8: pointer form
     constexpr int NS = (VAR & 2) ? 2 : 1;     // 32-row sub-blocks per wave: 2 = one wave per SIMD owning 64 query rows
     constexpr int NW = 8 / NS;                // waves per work-group (256 query rows either way)
@@ -875,6 +887,9 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
     bf16x8_t fr[HF];
     f32x16_t sA[NS], sB[NS];
     uint32_t pw[NS][8];
+    f32x4_t lsum = {0.f, 0.f, 0.f, 0.f};                                      // MSUM: every register = this lane's query's row sum
+    const uint32_t one2 = (((lane >> 4) ^ (lane >> 2)) & 1) ? 0u : 0x3f803f80u;        // MSUM: this lane's part of the ones pattern
+    const u32x4_t one4 = {one2, one2, one2, one2};
 
     // K fragments of key block `blk` (0/1) of tile t -> fr
     auto load_k_half = [&](int t, int blk) __attribute__((always_inline)) {
@@ -926,7 +941,7 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
                 for (int i = (8 * j) / HF; i < (8 * (j + 1)) / HF; ++i) {
                     const float a0 = AB_NOEXP ? cur[sb][2 * i] : __builtin_amdgcn_exp2f(cur[sb][2 * i]);
                     const float a1 = AB_NOEXP ? cur[sb][2 * i + 1] : __builtin_amdgcn_exp2f(cur[sb][2 * i + 1]);
-                    ls[sb] += a0 + a1;
+                    if (!MSUM) ls[sb] += a0 + a1;
                     pw[sb][i] = pack_bf16x2(a0, a1);
                 }
                 if (sb == NS - 1 && !AB_NODS) fr[j] = *(const bf16x8_t*)(vb + (j % DB) * 32 * 128 + vcoff[2 * hf + j / DB]);
@@ -951,8 +966,10 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
             // (round 3: moving this test out of the loop -- one test of l_run at the end bounds every half sum -- saves 3 VALU per half
             //  on paper; in the ring-unrolled build it tipped the register allocator over the 256-VGPR edge (296 B of scratch, 126
             //  scratch accesses per four tiles), so it stays.)
-            bad |= !(ls[sb] <= 0x1p96f);
-            l_run[sb] += ls[sb];
+            if (!MSUM) {
+                bad |= !(ls[sb] <= 0x1p96f);
+                l_run[sb] += ls[sb];
+            }
         }
         // ---- stage B: PV of half u, K fragments of half u+2 behind the MFMAs
         const char* kb = smem + (SL >= 0 ? ((SL + 1) & (ARING - 1)) : ((t + 1) & (ARING - 1))) * K_TILE_BYTES + hf * 32 * 256;      // half u+2 = tile t+1, same block
@@ -966,6 +983,8 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
                 if (AB_NOPV) asm volatile("" :: "v"(pf));
                 else if (NS == 2) fw_mfma_o_acc(o[sb][d], fr[i], pf);
                 else o[sb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pf, o[sb][d], 0, 0, 0);
+                if (MSUM && d == DB - 1)           // behind the last PV MFMA that reads this chunk of P^T
+                    lsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, one4), pf, lsum, 0, 0, 0);
             }
             if (NEXT2 && !AB_NODS) fr[i] = *(const bf16x8_t*)(kb + kcoff[i]);
             if (NS == 2) __builtin_amdgcn_sched_barrier(0);
@@ -1094,6 +1113,11 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         tile(nt - 1, SR{}, T_{});
     }
     if (NS == 2) fw_mfma_drain();
+    if (MSUM) {
+        // half of the total per half-wave, so that the combine below (l_run + its partner's) and the split-KV record stay as they are
+        bad |= !(lsum[0] <= 0x1p96f);
+        l_run[0] = 0.5f * lsum[0];
+    }
 
     if (__any(bad)) {
         // ---- exact recomputation of this wave's rows: plain online softmax, fragments straight from global memory.
@@ -1389,14 +1413,19 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
             return (int)hipGetLastError();
         }
     }
+    // round 6: the single-stream kernels take their row sums on the matrix pipe (attention_sp_kernel, VAR bit 9); FW_ATTN_VAR bit 11
+    // (2048) selects the round-5 choice for the A/B -- fp32 sums on the vector pipe, hd 96 on the two-segment ping-pong kernel
+    const bool vsum = ((fw_get_option(FW_OPT_ATTN_VAR) >> 11) & 1) != 0;
     int var = fw_get_option(FW_OPT_ATTN_VAR) & 255;     // 0 = first kernel (generic); 64.. = two-segment ping-pong; 128.. = single stream
     // 192 = per-head-dim choice among the pre-scaled kernels (microbench, profiles/r01/attention_sp_ablation.txt): the
     // single-stream kernel for hd 128 and hd 64, the two-segment ping-pong for hd 96
     // round 3: hd 128 / hd 64 on the ring-unrolled form of the single-stream kernel (193): -2.4 % / -4.6 % on one box
     // (profiles/r03/microbench_attention_unrolled.txt); hd 96 stays on the ping-pong kernel (its unrolled form spills)
     // (hd 64: the unrolled form WITHOUT the sched_group_barrier pins, 196: no scratch, 1.3 % faster than the pinned one)
-    if (var == 192) var = head_dim == 96 ? 64 : (head_dim == 64 ? 196 : 193);
-    if ((var & 64) && var >= 128 && head_dim == 96) var &= ~64;
+    // round 6: with the row sums off the vector pipe the unrolled single-stream kernel fits at hd 96 too (186 registers, no scratch)
+    // and beats the ping-pong kernel there by 8 % (profiles/r06/attn_ab_msum_call25.txt); hd 64 is faster pinned again
+    if (var == 192) var = vsum ? (head_dim == 96 ? 64 : (head_dim == 64 ? 196 : 193)) : 193;
+    if ((var & 64) && var >= 128 && head_dim == 96 && (vsum || (var & 2))) var &= ~64;      // (the vector-sum and four-wave forms have no unrolled hd-96 instantiation)
     if (prescaled && var >= 128) {
         // single-stream software pipeline on half tiles, pinned issue order; bit 1: one 64-row wave per SIMD (4 waves)
 #define FW_ATTN_SP(HDV, V) \
@@ -1407,9 +1436,12 @@ extern "C" int fw_attention_bf16(const uint16_t* Q, int64_t ldq, int64_t bsq,
         if (var & 64) {                                                                         // tile loop unrolled by the ring depth
             // (requests by descriptor need every byte offset of the (batch, head) view in 32 bits; else, and for the A/B, pointer form)
             const bool ptr_form = p.nofast || attn_view_needs_pointers(Lk, ldk, head_dim, Lk_pad);
-            if (ptr_form) { if (head_dim == 128) FW_ATTN_SP(128, 321); else FW_ATTN_SP(64, 320); }
+            if (var & 2) FW_ATTN_SP_HD_UNR(67);                // four waves of 64 rows (experiment arm; fp32 sums on the vector pipe)
+            else if (!vsum && ptr_form) FW_ATTN_SP_HD(321 + 512);
+            else if (!vsum && (var & 4)) FW_ATTN_SP_HD(64 + 512);
+            else if (!vsum) FW_ATTN_SP_HD(65 + 512);
+            else if (ptr_form) { if (head_dim == 128) FW_ATTN_SP(128, 321); else FW_ATTN_SP(64, 320); }
             else if (var & 4) FW_ATTN_SP_HD_UNR(64);          // 196: without the sched_group_barrier pins
-            else if (var & 2) FW_ATTN_SP_HD_UNR(67);
             else FW_ATTN_SP_HD_UNR(65);
         }
         else if (var & 2) FW_ATTN_SP_HD(3); else FW_ATTN_SP_HD(1);

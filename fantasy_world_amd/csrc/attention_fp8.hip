@@ -23,6 +23,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int QB = 256, KVB = 64, HD = 128;
 constexpr int K8_TILE = KVB * HD;        // 8 KiB: 64 rows x 128 B
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     constexpr bool V2 = (VAR & 512) != 0;         // round 6: the tile body in two basic blocks (below)
     constexpr bool REQ_PV = (VAR & 1024) != 0;    // V2: the tile requests ride between the PV MFMAs instead of opening the tile
     constexpr bool BAR2 = (VAR & 2048) != 0;      // V2: one barrier per TWO steady tiles
+    constexpr bool SUM16 = (VAR & 32768) != 0;    // V2: the row sums by ONE 16x16x128 MFMA (8 passes) instead of a 32x32x64 (16 passes)
     constexpr bool UNR8 = (VAR & 16384) != 0;     // V2 + BAR2: the steady loop unrolled by the ring depth (slot offsets become immediates)
     // the shift in the units of the score registers: the row's largest P is 2^7 when the shift is set (TOP) and the shift moves when a
     // score would pass 2^8 (OVF); UNIT = score units per power of two
@@ -951,6 +953,8 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         FW8_FENCE();
         if (MASK) mask_block(S1, t, 1);
         float mx;
+        // (Tried: ONE reduction per tile over both key blocks here instead of a second one at the end of the tile -- three vector
+        //  instructions fewer, the same time.)
         { const float m1 = row_max(S1); asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx0), "v"(m1)); }
         return mx;
     };
@@ -993,7 +997,22 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         // the tile's row sums: ones x P on the matrix pipe into the registers S1 has just released (C = 0), added to ONE register after the
         // PV MFMAs -- a resident 16-register accumulator whose registers all hold the same number does not fit beside the rest
         f32x16_t tsum;
-        if (!NOSUM) {
+        f32x4_t tsum4;
+        if (!NOSUM && SUM16) {
+            // HALF the matrix time: a 16x16x128 MFMA (8 passes) with a per-lane A operand.  In that shape lane l supplies B column l & 15,
+            // k-block l >> 4 -- so P of query fi (lanes fi and fi + 32) lands in column fi & 15, k-blocks (fi >> 4) and (fi >> 4) + 2: a
+            // column holds TWO queries (fi and fi ^ 16), on the even and on the odd k-blocks.  A row r of ones over the even k-blocks only
+            // sums the first, over the odd ones the second; the output rows 4 (l >> 4) .. + 3 that lane l reads must carry the sum of ITS
+            // query, fi = l & 31: rows 0-3 and 8-11 the even k-blocks, rows 4-7 and 12-15 the odd ones.  Lane l holds A row l & 15,
+            // k-block l >> 4: ones where the parity of the k-block equals the parity of (row >> 2), zeros elsewhere.
+            // (A in e4m3 here: tools/probes/mfma16_layout_probe.hip pins this lane -> row / k-block correspondence for e4m3 operands; with an
+            //  fp4 A operand the sums came out wrong)
+            const int on = (((lane >> 4) ^ (lane >> 2)) & 1) ? 0 : 0x38383838;
+            const i32x8_t ones = {on, on, on, on, on, on, on, on};
+            const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+            tsum4 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pf, zero4, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            FW8_FENCE();
+        } else if (!NOSUM) {
             // A = 1.0 in every e2m1 nibble (cbsz 4: the A operand is fp4, four registers instead of eight; B stays e4m3)
             // (the builtin takes eight; instruction selection keeps the four an fp4 operand has)
             const i32x8_t ones = {0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222, 0x22222222};
@@ -1019,7 +1038,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         o[3] = FW8_MFMA(fr[3], pf, o[3], 0x7f7f7f7f);
         if (NEXT2 && !NOLDS) fr[3] = k_frag(sl2, 0, 1);
         FW8_FENCE();
-        if (!NOSUM) l_run += tsum[0];
+        if (!NOSUM) l_run += SUM16 ? tsum4[0] : tsum[0];
         FW8_FENCE();
 #undef FW8_FENCE
         if (NEXT) {
@@ -1186,13 +1205,15 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
     const int64_t nwg = (int64_t)p.nqb * heads * batch;
     if (nwg > 0x7fffffff) { fw_set_error("fw_attention_fp8: grid too large"); return FW_E_BADARG; }
     // default (round 6): the single-stream kernel, linear-byte probabilities, two-block tile, requests between the PV MFMAs, one barrier
-    // per two tiles, steady loop unrolled by the ring depth.  A/B arms by FW_ATTN_VAR (tools/attn_fp8_ab.py) -- the steps that led there:
+    // per two tiles, steady loop unrolled by the ring depth, row sums by a 16x16x128 MFMA.  A/B arms by FW_ATTN_VAR (tools/attn_fp8_ab.py) -- the steps that led there:
     //   8 / 9    the in-phase kernel of round 2 / the two-group ping-pong kernel (rounds 2-4)
     //   12 / 13  round 5's kernel: exact exponential (v_exp_f32 + v_cvt_pk_fp8_f32), half-tile skew / all eight waves in phase
     //   14       + linear-byte probabilities (one v_cvt_pk_u8_f32 per score), round 5's tile body
     //   11       + the tile body in two basic blocks, in phase, row sums through a temporary accumulator   (bit-identical from here on)
     //   15       + tile requests between the PV MFMAs
     //   16       + one barrier per two tiles
+    //   17       + the steady loop unrolled by the ring depth
+    //   default  + the row sums by a 16x16x128 MFMA (half the matrix time of the 32x32x64 one)
     // Views of 4 GiB or more do not fit the descriptors' 32-bit byte offsets: they keep the ping-pong kernel (pointer requests).
     const int var = fw_get_option(FW_OPT_ATTN_VAR);
     const bool big = (uint64_t)Lk * (uint64_t)ldk >= 0xffffffffull || (uint64_t)head_dim * (uint64_t)lkp >= 0xffffffffull ||
@@ -1209,12 +1230,13 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
     else if (var == 11) FW8_LAUNCH((attention_fp8_sp_kernel<512 + 6>));
     else if (var == 15) FW8_LAUNCH((attention_fp8_sp_kernel<1024 + 512 + 6>));
     else if (var == 16) FW8_LAUNCH((attention_fp8_sp_kernel<2048 + 1024 + 512 + 6>));
+    else if (var == 17) FW8_LAUNCH((attention_fp8_sp_kernel<16384 + 2048 + 1024 + 512 + 6>));
 #ifdef FW8_KNOCKOUTS                 // timing-only arms of a tagged build (tools/attn_fp8_knockout.py): FW_ATTN_VAR = 1000 + knock-out bits
-#define FW8_KO(bits) else if (var == 1000 + (bits)) FW8_LAUNCH((attention_fp8_sp_kernel<16384 + 2048 + 1024 + 512 + 6 + (bits)>));
+#define FW8_KO(bits) else if (var == 1000 + (bits)) FW8_LAUNCH((attention_fp8_sp_kernel<32768 + 16384 + 2048 + 1024 + 512 + 6 + (bits)>));
     FW8_KO(8) FW8_KO(16) FW8_KO(32) FW8_KO(64) FW8_KO(256) FW8_KO(8 + 256) FW8_KO(16 + 32) FW8_KO(16 + 32 + 64) FW8_KO(8 + 16 + 32 + 64)
 #undef FW8_KO
 #endif
-    else FW8_LAUNCH((attention_fp8_sp_kernel<16384 + 2048 + 1024 + 512 + 6>));
+    else FW8_LAUNCH((attention_fp8_sp_kernel<32768 + 16384 + 2048 + 1024 + 512 + 6>));
 #undef FW8_LAUNCH
     return (int)hipGetLastError();
 }

@@ -68,16 +68,23 @@ int fw_abi_version(void);
                                   bit 2 = tile stamps only (tools/gemm_timeline.py); value >> 4 (if non-zero) = M-tiles per group of
                                   the tile order (default 4 for outputs >= 20 column tiles wide, else 8; tools/gemm_ab.py) */
 #define FW_OPT_ATTN_VAR    3   /* FW_ATTN_VAR: 192 (default) = per-head-dim choice among the log2-domain kernels that take q
-                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED): single-stream kernel with its tile
-                                   loop unrolled by the LDS ring depth (193; ring slots are compile-time, no address VALU in the
-                                   loop) for hd 128 / 64, two-segment ping-pong (64) for hd 96.  129 = single-stream, run-time
-                                   ring slots (the round-2 default); 131 / 195 = the same two with one 64-row wave per SIMD; 66 = TIMING build of the ping-pong kernel; 0 = the generic first kernel (also what calls
-                                   WITHOUT the pre-scaled flag get).  Bits 8-9 (added to any of the above): static wave priority
-                                   before the tile loop, 256 = waves 4..7, 512 = waves 0..3 (measured +-0, default off).
-                                   fw_attention_fp8 (round 5): default = the single-stream kernel (row sums by a ones-MFMA, the two waves
-                                   of a SIMD half a tile apart); 8 = the round-2 in-phase kernel, 9 = the two-group ping-pong kernel
-                                   (rounds 2-4 default; also serves views of 4 GiB or more), 10 = single stream with fp32 row sums
-                                   on the vector pipe, 11 = single stream with all eight waves in phase */
+                                   already multiplied by scale*log2(e) (FW_ATTN_Q_PRESCALED).  Round 6: for hd 128 / 96 / 64 the
+                                   single-stream kernel with its tile loop unrolled by the LDS ring depth (193; ring slots are
+                                   compile-time, no address VALU in the loop) and its row sums on the matrix pipe.  Bit 11 (2048, added
+                                   to any value): round 5's choice -- fp32 row sums on the vector pipe, hd 96 on the two-segment
+                                   ping-pong kernel (64) -- for the A/B.  129 = single-stream, run-time ring slots (the round-2
+                                   default; what the split-KV tails run); 131 / 195 = the same two with one 64-row wave per SIMD;
+                                   196 = 193 without the issue-order pins; 66 = TIMING build of the ping-pong kernel; 0 = the generic
+                                   first kernel (also what calls WITHOUT the pre-scaled flag get).  Bits 8-9: static wave priority
+                                   before the tile loop, 256 = waves 4..7, 512 = waves 0..3 (measured +-0, default off); bit 10
+                                   (1024): tile requests in the pointer form.
+                                   fw_attention_fp8: default (round 6) = the single-stream kernel with linear-byte probabilities, the
+                                   two-block tile, requests between the PV MFMAs, one barrier per two tiles, the steady loop unrolled
+                                   by the ring depth and row sums by a 16x16x128 MFMA; 17 / 16 / 15 / 11 = the same arithmetic (same
+                                   bits) without the last one / two / three / four of those steps; 14 = linear-byte probabilities in
+                                   round 5's tile body; 12 / 13 = round 5's kernel (exact exponential), the two waves of a SIMD half
+                                   a tile apart / in phase; 9 = the two-group ping-pong kernel (rounds 2-4; also serves views of 4 GiB
+                                   or more); 8 = the round-2 in-phase kernel */
 #define FW_OPT_COUNT       4
 int fw_set_option(int opt, int value);
 
@@ -389,7 +396,12 @@ int fw_fp8_quant_rows_amax(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t l
  * PARITY UNPINNED: the reference has no fp8 attention (its fp8 entry is the nn.Linear swap above), so these semantics are this
  * library's own: Q8 = e4m3(q * softmax_scale * log2(e) * 2^q_exp), K8 = e4m3(k) (both: fw_qk_prep, then fw_fp8_quant_rows with
  * raw = 1), Vt8 = fw_v_transpose_fp8(v); scores in fp32 (scaled MFMA, the 2^q_exp undone by the operand's block scale), online
- * softmax in fp32, P = e4m3(2^(s - m + 7)), O accumulated in fp32, written as bf16.  Opt-in (FusionEngine(fp8_attention=True)).
+ * softmax in fp32, O accumulated in fp32, written as bf16.  P (round 6): the e4m3 BYTE of the probability is
+ * round_to_nearest_even(8 (s - m + 7) + 56), saturated at 0 -- the e4m3 encoding of 2^(s - m + 7) with 2^f taken as 1 + f inside a
+ * binade (exact at the binade ends, at most 6.1 % high in between; the row sum is taken from the same bytes, so a constant factor
+ * cancels) -- one integer conversion per score instead of an exponential; FW_ATTN_VAR = 12 keeps P = e4m3(2^(s - m + 7)) for the A/B.
+ * m is a shift that keeps the row's largest P between 2^7 and 2^8 (it moves only when a later score would pass 2^8).
+ * Opt-in (FusionEngine(fp8_attention=True)).
  * ------------------------------------------------------------------------------------------------------------- */
 
 /* V [batch][Lk][heads*hd] bf16 (row stride ldv, batch stride bsv, elements) -> Vt8 [batch][heads][hd_out][lkp] e4m3 bytes,

@@ -227,11 +227,13 @@ class TorchRefOps:
             s = (qh.double() @ kh.double().transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else 1.0 / math.sqrt(hd))
             o = (torch.softmax(s, dim=-1) @ vh.double()).float()
         elif self.emulate_bf16 and self.emulate_p:
-            # the HIP kernels feed PV with P = 2^(s - m) ROUNDED to bf16 while the row sum adds the unrounded values (attention.hip):
-            # off in the default yardstick (HIP = 1.003 x floor without it), switched on by the per-site ablation to price it
+            # the HIP kernels feed PV with P = 2^(s - m) ROUNDED to bf16; since round 6 the row sum adds the SAME rounded values (a ones
+            # MFMA over the PV operand, attention.hip -- round 5 added the unrounded ones on the vector pipe): off in the default
+            # yardstick (HIP = 1.003 x floor without it), switched on by the per-site ablation to price it
             s = (qh @ kh.transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else 1.0 / math.sqrt(hd))
             pu = torch.exp(s - s.amax(dim=-1, keepdim=True))
-            o = (self._r(pu, f"attn_p:hd{hd}") @ vh) / pu.sum(dim=-1, keepdim=True)
+            pr = self._r(pu, f"attn_p:hd{hd}")
+            o = (pr @ vh) / pr.sum(dim=-1, keepdim=True)
         else:
             s = (qh @ kh.transpose(-1, -2)) * (0.6931471805599453 if q_prescaled else 1.0 / math.sqrt(hd))
             o = torch.softmax(s, dim=-1) @ vh

@@ -102,7 +102,9 @@ def test_hot_kernels_do_not_spill():
     if not os.path.exists(os.path.join(kernel_resources.LLVM, "llvm-readelf")):
         pytest.skip("ROCm LLVM tools not found")
     table = {name.replace("void ", ""): (vg, ag, lds, scr) for _, name, vg, ag, lds, scr in kernel_resources.all_kernels()}
-    must_be_clean = ["attention_fp8_sp_kernel<518>", "attention_sp_kernel<128, 65>", "attention_sp_kernel<128, 1>", "attention_sp_kernel<64, 1>", "attention_sp_kernel<96, 1>",
+    must_be_clean = ["attention_fp8_sp_kernel<518>", "attention_sp_kernel<128, 577>", "attention_sp_kernel<96, 577>", "attention_sp_kernel<64, 577>",
+                     "attention_sp_kernel<128, 833>", "attention_sp_kernel<96, 833>", "attention_sp_kernel<64, 833>",
+                     "attention_sp_kernel<128, 65>", "attention_sp_kernel<128, 1>", "attention_sp_kernel<64, 1>", "attention_sp_kernel<96, 1>",
                      "attention_pp3_kernel<96, 0>", "gemm_bf16_two_slot_kernel<0>", "gemm_bf16_four_slot_kernel<0, false>", "gemm_bf16_four_slot_kernel<0, true>",
                      "gemm_fp8_pp_kernel", "gemm_fp8_two_slot_kernel", "layernorm_lds_kernel<20, false, true>", "layernorm_lds_kernel<20, true, false>",
                      "layernorm_lds_kernel<4, true, true>", "qk_prep_wave_kernel<10, 1, 1, 0>", "qk_prep_wave_kernel<10, 1, 1, 1>",
@@ -111,7 +113,7 @@ def test_hot_kernels_do_not_spill():
         assert k in table, (k, sorted(table)[:5])
         assert table[k][3] == 0, f"{k}: {table[k][3]} bytes of scratch (vgpr {table[k][0]})"
         assert table[k][0] <= 256 and table[k][2] <= 160 * 1024
-    assert table["attention_sp_kernel<64, 64>"][3] == 0          # the hd-64 default (ring-unrolled, unpinned)
+    assert table["attention_sp_kernel<64, 64>"][3] == 0          # round 5's hd-64 default (ring-unrolled, unpinned), the A/B arm now
 
 
 def _disassemble(obj_name):
@@ -165,7 +167,7 @@ class _Listing(list):
         return out
 
 
-FP8_DEFAULT = "attention_fp8_sp_kernel<19974>"          # 16384 unrolled by the ring + 2048 pair barrier + 1024 requests in PV + 512 two-block tile + 4 linear byte + 2 in phase
+FP8_DEFAULT = "attention_fp8_sp_kernel<52742>"          # 32768 row sums by a 16x16x128 MFMA + 16384 unrolled by the ring + 2048 pair barrier + 1024 requests in PV + 512 two-block tile + 4 linear byte + 2 in phase
 
 
 def test_fp8_attention_steady_loop_has_no_scratch_traffic():
@@ -213,7 +215,7 @@ def test_fp8_attention_row_maximum_reads_mfma_results_behind_a_compiler_visible_
     every attention_fp8_sp_kernel instantiation is checked -- each v_max3 group is preceded by a v_readfirstlane of a register the group
     reads, with no MFMA that writes that block in between (the compiler pads that read with the s_nop the hazard needs)."""
     kernels = {k: v for k, v in _disassemble("attention_fp8").items() if "attention_fp8_sp_kernel" in k}
-    assert len(kernels) >= 7, sorted(k[:60] for k in kernels)      # the default and its six A/B arms (csrc/attention_fp8.hip: fw_attention_fp8)
+    assert len(kernels) >= 8, sorted(k[:60] for k in kernels)      # the default and its six A/B arms (csrc/attention_fp8.hip: fw_attention_fp8)
     groups = 0
     for name, ins in kernels.items():
         for i, text in enumerate(ins):

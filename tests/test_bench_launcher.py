@@ -95,7 +95,7 @@ def test_bench_matrix_pipe_blocks_are_stored_measurements_with_provenance():
         m = bench.attention_measured(hd)
         assert m is not None and 0.3 < m["mfma_busy"] < 1.0 and 1.0 < m["sustained_ghz"] < 2.4
         assert "stored PMC pass" in m["source"] and "profiles/r0" in m["source"]
-        assert abs(m["predicted_frac_of_2p5_pf"] - m["mfma_busy"] * m["sustained_ghz"] / 2.4) < 1e-3
+        assert abs(m["predicted_frac_of_2p5_pf"] - m["mfma_busy"] * m.get("algorithmic_share_of_mfma_cycles", 1.0) * m["sustained_ghz"] / 2.4) < 1e-3
     assert bench.attention_measured(80) is None          # no measurement, no number
 
 

@@ -355,6 +355,29 @@ def test_attention_descriptor_requests_return_the_bits_of_the_pointer_form(ops, 
     assert torch.isfinite(outs[0].float()).all()
 
 
+@pytest.mark.parametrize("heads,hd,Lq,Lk", [(3, 128, 700, 1333), (12, 96, 515, 1029), (16, 64, 600, 2100), (2, 128, 256, 64), (2, 64, 31, 7)])
+def test_attention_matrix_pipe_row_sums_against_vector_pipe_sums(ops, ref, heads, hd, Lq, Lk, parity, request):
+    """Round 6: the single-stream kernels sum the bf16-ROUNDED probabilities on the matrix pipe (v_mfma_f32_16x16x32_bf16 with a per-lane
+    ones pattern, csrc/attention.hip) where round 5 summed the unrounded fp32 p on the vector pipe (FW_ATTN_VAR bit 11 keeps that
+    choice, incl. the ping-pong kernel at hd 96, for the A/B).  Both against the fp32 softmax definition, and against each other: what
+    separates them is P's bf16 rounding in the denominator -- a wrong lane pattern (a query summed with its partner fi ^ 16) would
+    show as errors of order 1."""
+    D = heads * hd
+    q = bf(rnd(Lq, D, seed=51) * ops.q_scale(hd)).cuda()
+    k, v = bf(rnd(Lk, D, seed=52)).cuda(), bf(rnd(Lk, D, seed=53)).cuda()
+    want = ref.attention(q.cpu().float(), k.cpu().float(), v.cpu().float(), heads, hd, q_prescaled=True).float()
+    outs = []
+    try:
+        for var in (DEFAULT_ATTN_VAR, DEFAULT_ATTN_VAR + 2048):
+            ops.set_option("attn_var", var)
+            outs.append(ops.attention(q, k, v, heads, hd, q_prescaled=True).float().cpu())
+    finally:
+        ops.set_option("attn_var", DEFAULT_ATTN_VAR)
+    parity.check(f"op/{request.node.name}/matrix_pipe_sums_vs_fp32_softmax", rel_l2(outs[0], want), 8e-3)
+    parity.check(f"op/{request.node.name}/vector_pipe_sums_vs_fp32_softmax", rel_l2(outs[1], want), 8e-3)
+    parity.check(f"op/{request.node.name}/matrix_vs_vector_pipe_sums", rel_l2(outs[0], outs[1]), 4e-3)
+
+
 @pytest.mark.parametrize("gain", [3.0, 40.0])
 def test_attention_large_score_spike(attn_variant, ops, ref, gain, parity, request):
     """Online-softmax rescale path: a key whose score dwarfs the running max late in the sequence (gain 40: the spike is
@@ -766,9 +789,9 @@ def _digest_cases(ops):
             return ops.linear(x, lin, g1=rnd(N, seed=seed + 4).cuda(), res=stream, out_f32=True, out=stream, **epi)
         return ops.linear(x, lin, **epi)
     return {
-        "attention_sp_kernel<128,65>/H2_2100x2100": lambda: attn(2, 128, 2100, 2100, 11),
-        "attention_pp3_kernel<96,0>/H3_1500x1565": lambda: attn(3, 96, 1500, 1565, 21),
-        "attention_sp_kernel<64,64>/H4_1565x1565": lambda: attn(4, 64, 1565, 1565, 31),
+        "attention_sp_kernel<128,577>/H2_2100x2100": lambda: attn(2, 128, 2100, 2100, 11),
+        "attention_sp_kernel<96,577>/H3_1500x1565": lambda: attn(3, 96, 1500, 1565, 21),
+        "attention_sp_kernel<64,577>/H4_1565x1565": lambda: attn(4, 64, 1565, 1565, 31),
         "attention_fp8_sp_kernel<default>/H2_2100x2100": lambda: attn8(2, 2100, 2100, 41),
         "gemm_bf16_two_slot_kernel/2304x1536x1024_bias_gelu_bf16": lambda: gemm(2304, 1536, 1024, 51, act="gelu_tanh"),
         "gemm_bf16_two_slot_kernel/2304x1024x2048_gate_f32_residual": lambda: gemm(2304, 1024, 2048, 61, residual=True),
@@ -777,7 +800,8 @@ def _digest_cases(ops):
 
 
 def test_production_kernel_outputs_match_committed_digests(ops):
-    """sha256 of the outputs of the three production attention kernels, the fp8 attention kernel, the two-slot GEMM (two epilogues) and
+    """(Round 6: the three bf16 attention entries are the single-stream kernels with their row sums on the matrix pipe.)
+    sha256 of the outputs of the three production attention kernels, the fp8 attention kernel, the two-slot GEMM (two epilogues) and
     the fp8 GEMM on fixed seeds against tests/golden/kernel_digests_gfx950.json.  A mismatch means THE BUILD moved bits (hipcc version,
     compile flags, or a kernel edit that was meant to be bit-neutral): regenerate with FW_WRITE_DIGESTS=1 after checking the parity
     numbers, and say so in the commit.  Digests missing from the file are recorded to gpurun_out/ and reported as a skip."""

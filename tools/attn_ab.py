@@ -38,5 +38,6 @@ for (H, hd, Lq, Lk, tag) in shapes:
         med = statistics.median(times[x])
         line += f" var {x}: {med:.3f} ms = {4.0*Lq*Lk*H*hd/med/1e9:7.1f} TF/s (min {min(times[x]):.3f}) |"
     line += "  identical bits: " + str(all(torch.equal(outs[vs[0]], outs[x]) for x in vs[1:]))
+    line += "  rel-L2 vs the first: " + ", ".join(f"{((outs[x].float() - outs[vs[0]].float()).norm() / outs[vs[0]].float().norm()).item():.2e}" for x in vs[1:])
     print(line, flush=True)
 ops.set_option("attn_var", 192)

@@ -9,7 +9,8 @@ round 4's kernel to round 6's default, each arm adding one thing (csrc/attention
                     temporary accumulator, the shift updated register by register (no per-tile copies)
     15              + the tile requests between the PV MFMAs
     16              + one barrier per two tiles
-    default         + the steady loop unrolled by the ring depth (slot offsets are immediates)
+    17              + the steady loop unrolled by the ring depth (slot offsets are immediates)
+    default         + the row sums by a 16x16x128 MFMA with a per-lane ones operand (half the matrix time of the 32x32x64 one)
 and the bf16 kernel on the same shape as the yardstick.  Shapes: the DiT self-attention of BASELINE configs[1] (L = 32 760) and
 configs[4] (L = 111 600), 8 of the 40 heads (same work per work-group).  -> stdout (tools/gpu_pass.sh run: stage logs it)."""
 import os, statistics, sys
@@ -42,7 +43,8 @@ for L in (32760, 111600):
     vt = ops.prepare_v(v, H, hd)
     arms = {"9  ping-pong (rounds 2-4)": 9, "13 round 5, in phase": 13, "12 round 5, half-tile skew (its default)": 12,
             "14 + linear-byte probabilities": 14, "11 + two-block tile, in phase": 11, "15 + requests between the PV MFMAs": 15,
-            "16 + one barrier per two tiles": 16, "default: + unrolled by the ring depth": 192}
+            "16 + one barrier per two tiles": 16, "17 + unrolled by the ring depth": 17,
+            "default: + row sums by a 16x16x128 MFMA": 192}
     for extra in os.environ.get("EXTRA_VARS", "").split(","):
         if extra:
             arms[f"fp8 experiment var {extra}"] = int(extra)
