@@ -55,7 +55,8 @@ def predicted_block(n, mode, headline):
         return None
     best, worst = PREDICTED_STEP_MS[(n, mode)]
     return {"step_ms_best": best, "step_ms_worst": worst, "value_best": 1e3 / best, "value_worst": 1e3 / worst,
-            "source": "PREDICTION, not a measurement: profiles/r05/scaling_prediction.txt (tools/predict_scaling.py; tp with fp32 partial sums)"}
+            "source": "PREDICTION, not a measurement: profiles/r05/scaling_prediction.txt (tools/predict_scaling.py; tp with fp32 partial sums); "
+                      "built on round 5's one-GPU step of 3458 ms -- the round-6 attention kernels make the compute part ~2.5 % shorter"}
 
 
 def alt_budget_s(t_build_s, ms_per_step, n_alt, n_experts):

@@ -1208,6 +1208,13 @@ __global__ __launch_bounds__((VAR & 2) ? 256 : 512, (VAR & 2) ? 1 : 2) void atte
         }
         return;
     }
+    if (NS == 1) {
+        // The accumulators are FINAL before the only divergent branch of the kernel (round 6): an MFMA that the compiler sinks into the
+        // rows-below-Lq guard would run under a partial EXEC, and that returns garbage (seen in one fp8 instantiation, csrc/attention_fp8.hip).
+        // hipcc does not do it to this kernel today; this keeps it from ever doing it.
+#pragma unroll
+        for (int d = 0; d < DB; ++d) asm volatile("" : "+v"(o[0][d]));
+    }
 #pragma unroll
     for (int sb = 0; sb < NS; ++sb) {
         const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);

@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     if (VALU_SUM) l_tot = l_run + __shfl_xor(l_run, 32, 64);
     else if (V2) l_tot = NOSUM ? 1.0f : l_run;
     else l_tot = NOSUM ? 1.0f : osum[0];           // every accumulator register of the ones-MFMA holds this lane's query's row sum
-    if (V2) {
+    {
         // the accumulators are FINAL before the only divergent branch of the kernel: without this the compiler sinks the last tile's
         // MFMAs into the rows-below-Lq guard (MFMAs under a partial EXEC; the in-phase instantiation returned garbage for every wave that
         // holds rows past Lq)

@@ -399,7 +399,8 @@ int fw_fp8_quant_rows_amax(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t l
  * softmax in fp32, O accumulated in fp32, written as bf16.  P (round 6): the e4m3 BYTE of the probability is
  * round_to_nearest_even(8 (s - m + 7) + 56), saturated at 0 -- the e4m3 encoding of 2^(s - m + 7) with 2^f taken as 1 + f inside a
  * binade (exact at the binade ends, at most 6.1 % high in between; the row sum is taken from the same bytes, so a constant factor
- * cancels) -- one integer conversion per score instead of an exponential; FW_ATTN_VAR = 12 keeps P = e4m3(2^(s - m + 7)) for the A/B.
+ * cancels) -- one integer conversion per score instead of an exponential; FW_ATTN_VAR = 12 keeps P = e4m3(2^(s - m + 7)) for the A/B,
+ * and views of 4 GiB or more (served by the round-2..4 ping-pong kernel) still use it.
  * m is a shift that keeps the row's largest P between 2^7 and 2^8 (it moves only when a later score would pass 2^8).
  * Opt-in (FusionEngine(fp8_attention=True)).
  * ------------------------------------------------------------------------------------------------------------- */
