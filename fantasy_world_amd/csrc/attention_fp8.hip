@@ -11,8 +11,11 @@
 //                                (more of e4m3's range for the small pre-scaled q), undone exactly by the B-operand block scale 2^-3
 //   O^T[d][q]  += Vt_tile P^T   4 d blocks x 1 MFMA (k = the tile's 64 keys); P = 2^(s - m + 7) in e4m3 (values up to 128; the
 //                                factor 2^7 is carried by the row sum as well and cancels in O / l)
-// Half the matrix cycles of the bf16 kernel for the same softmax work: the kernel is bound by the exponentials, like the bf16
-// kernel at head_dim 64.
+// Half the matrix cycles of the bf16 kernel for the same softmax work, so the vector side decides: rounds 2-5 were bound by the
+// exponentials; the round-6 default (attention_fp8_sp_kernel, VAR 52742) takes P's e4m3 BYTE as round(8 log2 P + 56) by one integer
+// conversion per score, runs the tile as two basic blocks, sums the rows by a 16x16x128 MFMA and reaches 0.53-0.55 of the fp8 peak
+// (docs/kernels.md, "fp8 attention, round 6, second half"; the kernels in this file are kept in the order they were written:
+// attention_fp8_kernel (round 2), attention_fp8_pp_kernel (rounds 2-4), attention_fp8_sp_kernel (rounds 5-6, all its A/B arms).
 // LDS: K tile 64 keys x 128 B, Vt tile 128 d-rows x 64 B (keys of a tile in the order the score registers hold them:
 // fw_v_transpose_fp8 bakes the permutation in), 4-slot rings filled by global_load_lds_dwordx4 with the swizzle on the source
 // address, one barrier per tile, counted vmcnt (tile t+3 is requested in iteration t).
