@@ -249,6 +249,39 @@ def test_merged_cfg_pair_equals_two_forwards(case_name, request):
     assert rel_l2(b, a) < 1e-6
 
 
+def test_fp8_attention_statement_linear_byte_against_the_exact_exponential():
+    """Round 6: the kernel's probabilities are the e4m3 BYTE round(8 (s - m + 7) + 56) (2^f taken as 1 + f inside a binade; one integer
+    conversion per score, csrc/attention_fp8.hip) -- the CPU statement follows (TorchRefOps.fp8_linear_exp, the default).  Here, on the
+    statement alone: every byte stays inside e4m3's finite positive range, the largest probability of a row is 2^7, bytes are monotone
+    in the score, the byte decodes to within (1 + f) / 2^f <= 6.2 % above -- never below by more than half a byte -- the exact
+    exponential, and the attention output stays within e4m3 noise of the exact-exponential statement."""
+    import torch
+    from oracle.ref_ops import TorchRefOps
+    x = torch.linspace(-20.0, 0.0, 4001, dtype=torch.float64)               # s - m
+    bits = torch.round(8.0 * x.float() + 112.0).clamp(0, 255).to(torch.uint8)
+    assert int(bits.max()) == 0x70 and int(bits.min()) == 0 and bool((bits[1:] >= bits[:-1]).all())
+    val = bits.view(torch.float8_e4m3fn).to(torch.float64)
+    exact = torch.exp2(x + 7.0)
+    normal = bits >= 8
+    ratio = (val / exact)[normal]
+    assert float(ratio.max()) < 1.0615 * 1.045 and float(ratio.min()) > 0.955, (float(ratio.min()), float(ratio.max()))   # 1 + f vs 2^f, +- half a byte
+    assert float(val[128]) == 0.0                                            # 14 binades below the maximum: flushed like e4m3(2^x) would be
+
+    g = torch.Generator().manual_seed(5)
+    H, hd, Lq, Lk = 2, 128, 96, 700
+    ops = TorchRefOps(exact=True)
+    q = torch.randn(Lq, H * hd, generator=g) * ops.q_scale_fp8(hd)
+    k, v = torch.randn(Lk, H * hd, generator=g), torch.randn(Lk, H * hd, generator=g)
+    q8, k8 = ops.cast_fp8(q), ops.cast_fp8(k)
+    v8, _ = ops.prepare_v_fp8(v, H, hd)
+    outs = {}
+    for lin in (True, False):
+        ops.fp8_linear_exp = lin
+        outs[lin] = ops.attention_fp8(q8, k8, v8, H, hd, Lk).float()
+    e = rel_l2(outs[True], outs[False])
+    assert 0 < e < 6e-2, e                 # two realisations of P's 3-bit rounding (the GPU arms measure 2.1-4.1e-2, same bound)
+
+
 def test_fp8_attention_engine_on_its_cpu_statement(case_l2):
     """fp8 attention has no reference semantics (the reference defines fp8 for nn.Linear only).  Its CPU statement in the test op set
     (oracle/ref_ops.py: the semantics include/fw_mi355x.h states) exists so that the HOST orchestration -- what is cast where, what the
