@@ -1,5 +1,5 @@
 """Ragged-shape check of fw_attention_fp8 A/B arms against the default kernel: rows past Lq, a last tile with a handful of keys, one-tile
-sequences -- the shapes on which an MFMA sunk under a partial EXEC showed (docs/kernels.md).  VARS=17,16,15,11,14 python tools/probes/dbg_fp8_v2.py"""
+sequences -- the shapes on which an MFMA sunk under a partial EXEC showed (docs/kernels.md).  VARS=17,16,15,11,14 python tools/probes/fp8_attention_ragged_arms.py"""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from fantasy_world_amd.hip_ops import HipOps
