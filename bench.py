@@ -87,6 +87,9 @@ def parse_args(argv=None):
     ap.add_argument("--fp8-bicross", action="store_true",
                     help="with --fp8-attention, N = 1: the bicross attention (hd 96) on e4m3 operands as well, through the hd-128 kernel on "
                          "zero-padded heads (round-6 experiment; parity unpinned, measured under the same 2e-2; never the headline)")
+    ap.add_argument("--fp8-vggt", action="store_true",
+                    help="with --fp8-attention, N = 1: --fp8-bicross plus the VGGT frame / global attention (hd 64) on fw_attention_fp8's "
+                         "head_dim-64 kernel (round-6 experiment; parity unpinned, measured under the same 2e-2; never the headline)")
     ap.add_argument("--cache-invariants", action="store_true")
     ap.add_argument("--merge-cfg", action="store_true", help="N = 1: the two CFG forwards of a step as ONE pass over 2L rows")
     ap.add_argument("--experts", type=int, default=None, help="wan22: resident experts (default 2; 1 = high-noise only)")
@@ -334,7 +337,7 @@ def main():
     t0 = time.time()
     engines = [parallel.make_engine(cfg, lambda n, s=s: synth.make_param(n, spec[n][0], spec[n][1], device=dev, seed=s), ops, topo,
                                     cache_step_invariants=args.cache_invariants, precision=args.precision,
-                                    **({"fp8_attention": "bicross" if args.fp8_bicross else True} if args.fp8_attention else {}))
+                                    **({"fp8_attention": "all" if args.fp8_vggt else ("bicross" if args.fp8_bicross else True)} if args.fp8_attention else {}))
                for s in range(n_experts)]
     torch.cuda.synchronize()
     t_build = time.time() - t0
@@ -504,7 +507,7 @@ def main():
         "metric": metric,
         "value": value, "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("fp8_e4m3 linears (fp32 accumulate), " + (("fp8_e4m3 DiT self-attention" + (" and bicross attention" if getattr(eng, "fp8_bicross", False) else "")
+        "dtype": ("fp8_e4m3 linears (fp32 accumulate), " + (("fp8_e4m3 DiT self-attention" + (" and bicross attention" if getattr(eng, "fp8_bicross", False) else "") + (" and VGGT frame / global attention" if getattr(eng, "fp8_vggt", False) else "")
                                                            + " (fp32 scores / softmax / accumulate; parity unpinned)")
                                                           if fp8_attn else "bf16 attention"))
                  if args.precision == "fp8" else "bf16", "data": "synthetic",

@@ -572,6 +572,7 @@ constexpr int RING_SP = 8;
 // the dependency is made visible: a v_readfirstlane of v[0] -- an ordinary VALU read of the same MFMA's destination, for which the
 // compiler inserts exactly the s_nop the hazard needs -- whose result is an (unused) input of the asm, which orders it in front.
 // Once that read may issue, the MFMA has retired all 16 registers.  tests/test_abi.py checks the compiled code for the pair.
+__device__ __forceinline__ float fw8_whole_binades(float x);
 __device__ __forceinline__ float fw8_max16(const f32x16_t& v) {
     float r, t;
 #ifdef FW8_NO_MAX_GUARD                            // A/B build only (tools/lib_ab.py): what the guard costs
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         const int sl1 = SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : ((t + 1) & (RING_SP - 1));
         const int sl2 = SLT >= 0 ? ((SLT + 2) & (RING_SP - 1)) : ((t + 2) & (RING_SP - 1));
         if (__builtin_expect(__any(mx0 > OVF), 0)) {    // block 0 would overflow e4m3: move the shift so that the largest P is 2^7 again
-            const float delta = fmaxf(mx0 - TOP, 0.f);
+            const float delta = LIN ? fw8_whole_binades(fmaxf(mx0 - TOP, 0.f)) : fmaxf(mx0 - TOP, 0.f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) S0[r] -= delta;
             rescale(delta);
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
         {
             const float mx1 = row_max(S1);
             if (__builtin_expect(__any(mx1 > OVF), 0)) {       // rare: block 1 would overflow e4m3 under the tile's shift -- redo block 0
-                const float delta = fmaxf(mx1 - TOP, 0.f);
+                const float delta = LIN ? fw8_whole_binades(fmaxf(mx1 - TOP, 0.f)) : fmaxf(mx1 - TOP, 0.f);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
                 rescale(delta);
@@ -963,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     };
     // rare: a score of this tile would overflow e4m3 under the shift -- move it, redo block 0's probabilities (S0 is intact until block 2)
     auto tile2_repair = [&](float mx) __attribute__((always_inline)) {
-        const float delta = fmaxf(mx - TOP, 0.f);
+        const float delta = LIN ? fw8_whole_binades(fmaxf(mx - TOP, 0.f)) : fmaxf(mx - TOP, 0.f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; }
         rescale(delta);
@@ -1073,6 +1074,7 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     S1 = FW8_MFMA(fr[1], qf[1], S1, qs);
     if (ragged && nt == 1) { mask_block(S0, 0, 0); mask_block(S1, 0, 1); }
     M = fmaxf(row_max(S0), row_max(S1)) - TOP;    // the first tile's largest P is 2^7 (tile 0 recomputes S1 under this shift)
+    if (LIN) M = fw8_whole_binades(M);            // ... or up to one binade below it: the shift is a whole number of binades
     set_negM();
 #pragma unroll
     for (int r = 0; r < 16; ++r) S0[r] -= M;
@@ -1165,6 +1167,278 @@ __global__ __launch_bounds__(512, 2) void attention_fp8_sp_kernel(Attn8Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// head_dim 64 (round 6): the VGGT global attention of BASELINE config 5.  attention_fp8_sp_kernel's default arm (linear-byte
+// probabilities, two-block tile with one overflow test, requests beside the PV MFMAs, one barrier per two tiles, steady loop unrolled by
+// the ring depth, 16x16x128 row sums), written out for 64-byte K rows and 64 Vt rows: ONE QK^T MFMA per key block (k = 64 = the head), TWO
+// PV MFMAs per tile -- 4.5 MFMA-equivalents per tile instead of 8.5 for the same vector work.  A K tile and a Vt tile are 4 KiB each =
+// four 1 KiB request pieces: waves 0-3 request K, waves 4-7 Vt, one request per wave and tile (so the waits at a barrier leave one /
+// two requests per wave in flight instead of two / four).  168 registers, no scratch (at 128 registers -- two work-groups per CU in the
+// 64 KiB of LDS each needs -- the steady loop spills 220 times per eight tiles: not instantiated).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int HD64 = 64;
+constexpr int K64_TILE = KVB * HD64;       // 4 KiB: 64 rows x 64 B
+constexpr int V64_TILE = HD64 * KVB;       // 4 KiB: 64 rows x 64 B
+
+// The shift of the linear-byte kernels moves by WHOLE BINADES (multiples of 8 score units).  The byte -> value map is exponential only
+// from binade to binade (inside one the mantissa is linear), so byte + 8 j decodes to exactly 2^j times byte's value, while byte + 1 does
+// NOT decode to 2^(1/8) times it: with whole-binade shifts the probabilities of a row are the same set of numbers, up to one common
+// power of two, WHATEVER tile the shift last moved in -- the result does not depend on the shift's history (up to which tiny weights
+// fall below e4m3's range), and the kernel agrees with its CPU statement (true row maximum, oracle/ref_ops.py) to fp32 rounding
+// instead of to "another realisation of P's rounding" (3.8e-2 before).
+__device__ __forceinline__ float fw8_whole_binades(float x) { return 8.0f * ceilf(x * 0.125f); }
+
+// 8 scores s[8g .. 8g+7] -> two words of e4m3 bytes round(score) (csrc comment at attention_fp8_sp_kernel: "THE EXPONENTIAL IS AN
+// INTEGER CONVERSION")
+__device__ __forceinline__ void fw8_cvt8(const f32x16_t& s, int g, int& w0, int& w1) {
+    unsigned x = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g], 0, __float_as_uint(s[8 * g]));
+    x = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 1], 1, x);
+    x = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 2], 2, x);
+    w0 = (int)__builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 3], 3, x);
+    unsigned y = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 4], 0, __float_as_uint(s[8 * g + 4]));
+    y = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 5], 1, y);
+    y = __builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 6], 2, y);
+    w1 = (int)__builtin_amdgcn_cvt_pk_u8_f32(s[8 * g + 7], 3, y);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(512, MINW) void attention_fp8_hd64_kernel(Attn8Args p) {
+    __shared__ __attribute__((aligned(16))) char smem[RING_SP * (K64_TILE + V64_TILE)];      // 64 KiB
+    constexpr int V_BASE = RING_SP * K64_TILE;
+    constexpr float TOP = 112.0f, OVF = 120.5f;          // score units: eighths of a power of two, bias 56 (see attention_fp8_sp_kernel)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 31, hi = lane >> 5;
+
+    int item;
+    {
+        const int nwg = gridDim.x;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, slot = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int bh = item / p.nqb;
+    const int qb = item - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const uint8_t* Qp = p.Q + (int64_t)b * p.bsq + (int64_t)h * HD64;
+    const uint8_t* Kp = p.K + (int64_t)b * p.bsk + (int64_t)h * HD64;
+    const uint8_t* Vp = p.Vt + ((int64_t)b * p.heads + h) * HD64 * p.lkp;
+    uint16_t* Op = p.O + (int64_t)b * p.bso + (int64_t)h * HD64;
+
+    const int q_row = qb * QB + wave * 32 + fi;
+    i32x8_t qf;
+    {
+        const uint8_t* src = Qp + (int64_t)min(q_row, p.Lq - 1) * p.ldq + hi * 32;
+        qf = frag32((const char*)src, (const char*)src + 16);
+    }
+    const int nt = (p.Lk + KVB - 1) / KVB;
+    const bool ragged = (p.Lk & (KVB - 1)) != 0;
+    const int qs = p.q_scale_e8m0 + 0x03030303;          // scores in eighths
+
+    // ---- tile requests: waves 0-3 one 1 KiB K piece (16 key rows), waves 4-7 one 1 KiB Vt piece (16 d rows); the swizzle sits on the
+    // source address (an LDS-DMA request writes its lanes contiguously)
+    const bool kwave = wave < 4;
+    const int rrow = (wave & 3) * 16 + (lane >> 2);
+    const int rchunk = ((lane & 3) ^ ((rrow >> 2) & 3)) << 4;
+    const int roff = rrow * (kwave ? (int)p.ldk : (int)p.lkp) + rchunk;
+    const size_t kbytes = (size_t)p.Lk * (size_t)p.ldk, vbytes = (size_t)HD64 * (size_t)p.lkp;
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(unsigned)kbytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(unsigned)vbytes, 0x00020000);
+    const int k_tile_stride = KVB * (int)p.ldk;
+    // K(tk) into ring slot sk by waves 0-3, Vt(tv) into slot sv by waves 4-7 (tiles clamped to the last one: the count stays constant)
+    auto issue = [&](int tk, int sk, int tv, int sv) __attribute__((always_inline)) {
+        if (kwave) __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, FW_LDS_PTR(smem + (sk & (RING_SP - 1)) * K64_TILE + (wave & 3) * 1024), 16, roff,
+                                                            min(tk, nt - 1) * k_tile_stride, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, FW_LDS_PTR(smem + V_BASE + (sv & (RING_SP - 1)) * V64_TILE + (wave & 3) * 1024), 16, roff,
+                                                      min(tv, nt - 1) * KVB, 0, 0);
+    };
+    // fragment read offsets (rows of 64 B; the same swizzle for K and Vt)
+    int fco[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) fco[e] = fi * 64 + (((2 * hi + e) ^ ((fi >> 2) & 3)) << 4);
+    auto k_frag = [&](int slot, int blk) __attribute__((always_inline)) {
+        const char* base = smem + slot * K64_TILE + blk * 32 * 64;
+        return frag32(base + fco[0], base + fco[1]);
+    };
+    auto v_frag = [&](int slot, int d) __attribute__((always_inline)) {
+        const char* base = smem + V_BASE + slot * V64_TILE + d * 32 * 64;
+        return frag32(base + fco[0], base + fco[1]);
+    };
+
+    f32x16_t o[2], negM, S0, S1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { negM[r] = 0.f; o[0][r] = 0.f; o[1][r] = 0.f; }
+    float M = 0.f, l_run = 0.f, mx0 = 0.f;
+    i32x8_t fr[2];                           // fr[0]: K1(t) -> Vt d-block 0 -> K1(t+1);  fr[1]: K0(t+1) -> Vt d-block 1 -> K0(t+2)
+    int pw[8];
+    const int on = (((lane >> 4) ^ (lane >> 2)) & 1) ? 0 : 0x38383838;       // this lane's part of the row-sum pattern (sp kernel, SUM16)
+
+    auto mask_block = [&](f32x16_t& s, int t, int blk) __attribute__((always_inline)) {
+        const int kbase = t * KVB + blk * 32 + 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (kbase + (r & 3) + 8 * (r >> 2) >= p.Lk) s[r] = -1.0e30f;
+    };
+    auto row_max = [&](const f32x16_t& s) __attribute__((always_inline)) {
+        const float mx = fw8_max16(s);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(sw[0]), "v"(sw[1]));
+        return r;
+    };
+    auto sync = [&](auto pair_tag) __attribute__((always_inline)) {
+        if (decltype(pair_tag)::value) fw8_wait_vm<1>(); else fw8_wait_vm<2>();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#define FW8_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // block 1 of tile t: S1(t)  ||  P of key block 0, Vt d-block 0; returns the tile's largest score under the current shift
+    auto tile_a = [&](int t, auto mask_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr int SLT = decltype(slot_tag)::value;
+        const int sl = SLT >= 0 ? SLT : (t & (RING_SP - 1));
+        FW8_FENCE();
+        S1 = FW8_MFMA(fr[0], qf, negM, qs);
+        FW8_FENCE();
+        fw8_cvt8(S0, 0, pw[0], pw[1]);
+        fw8_cvt8(S0, 1, pw[2], pw[3]);
+        fr[0] = v_frag(sl, 0);
+        asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]));
+        FW8_FENCE();
+        if (MASK) mask_block(S1, t, 1);
+        float mx;
+        { const float m1 = row_max(S1); asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx0), "v"(m1)); }
+        return mx;
+    };
+    auto repair = [&](float mx) __attribute__((always_inline)) {          // rare: move the shift, redo key block 0's probabilities
+        const float delta = fw8_whole_binades(fmaxf(mx - TOP, 0.f));
+        const float alpha = __builtin_amdgcn_exp2f(-delta * 0.125f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S0[r] -= delta; S1[r] -= delta; negM[r] -= delta; o[0][r] *= alpha; o[1][r] *= alpha; }
+        l_run *= alpha;
+        M += delta;
+        fw8_cvt8(S0, 0, pw[0], pw[1]);
+        fw8_cvt8(S0, 1, pw[2], pw[3]);
+    };
+    // block 2: S0(t+1)  ||  P of key block 1, Vt d-block 1; row sums + PV (2.5 MFMAs)  ||  requests, K fragments, row maximum of S0(t+1)
+    auto tile_b = [&](int t, auto next_tag, auto next2_tag, auto maskn_tag, auto sync_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(next_tag)::value, NEXT2 = decltype(next2_tag)::value, MASKN = decltype(maskn_tag)::value;
+        constexpr int SYNC = decltype(sync_tag)::value, SLT = decltype(slot_tag)::value;
+        const int sl = SLT >= 0 ? SLT : (t & (RING_SP - 1)), sl1 = SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : ((t + 1) & (RING_SP - 1));
+        const int sl2 = SLT >= 0 ? ((SLT + 2) & (RING_SP - 1)) : ((t + 2) & (RING_SP - 1));
+        FW8_FENCE();
+        if (NEXT) S0 = FW8_MFMA(fr[1], qf, negM, qs);
+        FW8_FENCE();
+        fw8_cvt8(S1, 0, pw[4], pw[5]);
+        fw8_cvt8(S1, 1, pw[6], pw[7]);
+        fr[1] = v_frag(sl, 1);
+        FW8_FENCE();
+        const i32x8_t pf = {pw[0], pw[1], pw[2], pw[3], pw[4], pw[5], pw[6], pw[7]};
+        const i32x8_t ones = {on, on, on, on, on, on, on, on};
+        const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4_t tsum4 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ones, pf, zero4, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        FW8_FENCE();
+        o[0] = FW8_MFMA(fr[0], pf, o[0], 0x7f7f7f7f);
+        if (NEXT) fr[0] = k_frag(sl1, 1);
+        if (NEXT) issue(t + 5, SLT >= 0 ? SLT + 5 : t + 5, t + 3, SLT >= 0 ? SLT + 3 : t + 3);
+        FW8_FENCE();
+        o[1] = FW8_MFMA(fr[1], pf, o[1], 0x7f7f7f7f);
+        if (NEXT2) fr[1] = k_frag(sl2, 0);
+        FW8_FENCE();
+        l_run += tsum4[0];
+        FW8_FENCE();
+        if (NEXT) {
+            if (MASKN) mask_block(S0, t + 1, 0);
+            mx0 = row_max(S0);
+            if (SYNC) sync(std::integral_constant<bool, SYNC == 2>{});
+        }
+    };
+#undef FW8_FENCE
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    using SR = std::integral_constant<int, -1>;
+    using Y0 = std::integral_constant<int, 0>;
+    using Y1 = std::integral_constant<int, 1>;
+    using Y2 = std::integral_constant<int, 2>;
+
+    // ---- prologue: K(0..4) / Vt(0..2) requested; both key blocks of S(0) for the shift; then the fragments tile 0 starts from
+    issue(0, 0, 0, 0);
+    issue(1, 1, 1, 1);
+    issue(2, 2, 2, 2);
+    if (kwave) { issue(3, 3, 0, 0); issue(4, 4, 0, 0); }
+    fw8_wait_vm<0>();
+    FW8_BARRIER();
+    S0 = FW8_MFMA(k_frag(0, 0), qf, negM, qs);
+    fr[0] = k_frag(0, 1);
+    S1 = FW8_MFMA(fr[0], qf, negM, qs);
+    if (ragged && nt == 1) { mask_block(S0, 0, 0); mask_block(S1, 0, 1); }
+    M = fw8_whole_binades(fmaxf(row_max(S0), row_max(S1)) - TOP);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { negM[r] = -M; S0[r] -= M; }
+    mx0 = TOP;
+    if (nt > 1) fr[1] = k_frag(1, 0);
+
+    auto pair = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int SLT = decltype(slot_tag)::value;
+        using NXT = std::integral_constant<int, (SLT >= 0 ? ((SLT + 1) & (RING_SP - 1)) : -1)>;
+        float mx = tile_a(t, F_{}, slot_tag);
+        if (__builtin_expect(__any(mx > OVF), 0)) repair(mx);
+        tile_b(t, T_{}, T_{}, F_{}, Y0{}, slot_tag);
+        mx = tile_a(t + 1, F_{}, NXT{});
+        if (__builtin_expect(__any(mx > OVF), 0)) repair(mx);
+        tile_b(t + 1, T_{}, T_{}, F_{}, Y2{}, NXT{});
+    };
+    int t = 0;
+#pragma unroll 1
+    for (; t + 9 < nt; t += 8) {              // eight steady tiles: t is a multiple of the ring depth, the slots are immediates
+        pair(t, std::integral_constant<int, 0>{});
+        pair(t + 2, std::integral_constant<int, 2>{});
+        pair(t + 4, std::integral_constant<int, 4>{});
+        pair(t + 6, std::integral_constant<int, 6>{});
+    }
+#pragma unroll 1
+    for (; t + 3 < nt; t += 2) pair(t, SR{});
+#pragma unroll 1
+    for (; t + 2 < nt; ++t) {                 // a steady tile on its own (two successors)
+        const float mx = tile_a(t, F_{}, SR{});
+        if (__builtin_expect(__any(mx > OVF), 0)) repair(mx);
+        tile_b(t, T_{}, T_{}, F_{}, Y1{}, SR{});
+    }
+    if (t + 1 < nt) {                         // second-last tile
+        const float mx = tile_a(t, F_{}, SR{});
+        if (__builtin_expect(__any(mx > OVF), 0)) repair(mx);
+        if (ragged) tile_b(t, T_{}, F_{}, T_{}, Y1{}, SR{}); else tile_b(t, T_{}, F_{}, F_{}, Y1{}, SR{});
+        ++t;
+    }
+    {                                         // last tile
+        const float mx = ragged ? tile_a(t, T_{}, SR{}) : tile_a(t, F_{}, SR{});
+        if (__builtin_expect(__any(mx > OVF), 0)) repair(mx);
+        tile_b(t, F_{}, F_{}, F_{}, Y1{}, SR{});
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l.  The accumulators are final BEFORE the only divergent branch (no MFMA under a partial EXEC).
+    float l_tot = l_run;
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(l_tot));
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Lq) {
+        uint16_t* dst = Op + (int64_t)q_row * p.ldo;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = d * 32 + 8 * g + 4 * hi;
+                u32x2_t w = {pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv), pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
+                *(u32x2_t*)(dst + col) = w;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int fw_v_transpose_fp8(const uint16_t* V, int64_t ldv, int64_t bsv, uint8_t* Vt8, int64_t lkp, int batch, int heads,
@@ -1194,7 +1468,7 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
                                 int batch, int heads, int head_dim, int Lq, int Lk, int q_exp, void* stream) {
     if (batch <= 0 || heads <= 0 || Lq <= 0) return 0;
     if (Lk <= 0) { fw_set_error("fw_attention_fp8: Lk must be > 0"); return FW_E_BADARG; }
-    if (head_dim != 128) { fw_set_error("fw_attention_fp8: head_dim must be 128"); return FW_E_UNSUPPORTED; }
+    if (head_dim != 128 && head_dim != 64) { fw_set_error("fw_attention_fp8: head_dim must be 128 or 64"); return FW_E_UNSUPPORTED; }
     if (q_exp < 0 || q_exp > 16) { fw_set_error("fw_attention_fp8: q_exp out of range"); return FW_E_BADARG; }
     if ((ldq % 16) || (ldk % 16) || (bsq % 16) || (bsk % 16) || (ldo % 4) || (bso % 4) || (lkp % 64) || lkp < Lk ||
         (((uintptr_t)Q8) & 15) || (((uintptr_t)K8) & 15) || (((uintptr_t)Vt8) & 15) || (((uintptr_t)O) & 7)) {
@@ -1222,6 +1496,11 @@ extern "C" int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, con
     const bool big = (uint64_t)Lk * (uint64_t)ldk >= 0xffffffffull || (uint64_t)head_dim * (uint64_t)lkp >= 0xffffffffull ||
                      (uint64_t)(Lk + 6 * KVB) * (uint64_t)ldk >= 0x7fffffffull;
 #define FW8_LAUNCH(K) hipLaunchKernelGGL(K, dim3((unsigned)nwg), dim3(512), 0, (hipStream_t)stream, p)
+    if (head_dim == 64) {                   // round 6: one kernel, no older arms
+        if (big) { fw_set_error("fw_attention_fp8: head_dim 64 needs views below 4 GiB"); return FW_E_UNSUPPORTED; }
+        FW8_LAUNCH((attention_fp8_hd64_kernel<2>));
+        return (int)hipGetLastError();
+    }
     if (var == 8) FW8_LAUNCH(attention_fp8_kernel);
     else if (var == 9 || big) FW8_LAUNCH(attention_fp8_pp_kernel);
     // (FW_ATTN_VAR=10, the in-phase arm with fp32 row sums on the vector pipe, is gone since round 6: it was the slower arm, and under

@@ -219,7 +219,9 @@ def install(model, ops=None, device=None, cache_step_invariants=True, precision=
     tolerance is 2e-2 rel-L2 of noise_pred against the same engine with bf16 attention (measured 1.35e-2 at 40 / 24 / 24 blocks,
     INTEGRATION.md).  Both options work on one GPU and under either multi-GPU partition (`topo`).  `fp8_attention="bicross"`
     (one GPU; round-6 experiment): additionally the two directions of the bicross attention through the same kernel on zero-padded
-    heads -- measured 1.36e-2 against bf16 attention everywhere at 40 / 24 / 24 blocks, the same stated 2e-2.
+    heads -- measured 1.36e-2 against bf16 attention everywhere at 40 / 24 / 24 blocks, the same stated 2e-2; `fp8_attention="all"`
+    (one GPU; second half of round 6): additionally the VGGT frame / global attention (head_dim 64) on fw_attention_fp8's head_dim-64
+    kernel.
 
     Several GPUs (one process per GPU, every process running the SAME reference script on the same inputs): pass
     `topo=fantasy_world_amd.parallel.init_topology()` (or a bare `shard=SequenceShard(...)`).  The forward is then

@@ -401,7 +401,11 @@ int fw_fp8_quant_rows_amax(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t l
  * binade (exact at the binade ends, at most 6.1 % high in between; the row sum is taken from the same bytes, so a constant factor
  * cancels) -- one integer conversion per score instead of an exponential; FW_ATTN_VAR = 12 keeps P = e4m3(2^(s - m + 7)) for the A/B,
  * and views of 4 GiB or more (served by the round-2..4 ping-pong kernel) still use it.
- * m is a shift that keeps the row's largest P between 2^7 and 2^8 (it moves only when a later score would pass 2^8).
+ * m is a shift by a WHOLE NUMBER OF BINADES that keeps the row's largest byte in (104, 120] (set from the first tile, it moves only
+ * when a later score would pass 2^8.06): the byte -> value map is exponential from binade to binade only, so with whole-binade shifts
+ * the probabilities of a row are the same numbers up to one common power of two whatever the shift's history -- the kernel agrees with
+ * the CPU statement of these semantics (oracle/ref_ops.py::attention_fp8: true row maximum) to the bf16 rounding of its output
+ * (1.6-1.9e-3 rel-L2).  head_dim 128 (DiT self-attention; the bicross attention on heads zero-padded from 96) and 64 (VGGT).
  * Opt-in (FusionEngine(fp8_attention=True)).
  * ------------------------------------------------------------------------------------------------------------- */
 
@@ -429,7 +433,8 @@ int fw_qk_prep_fp8(const uint16_t* x, int64_t ldx, int rows, int heads, int head
                    int rope_mode, const float* rope_tab, int tab_rows, float out_scale,
                    const float* row_sumsq, int norm_width, uint8_t* out8, int64_t ld8, int head_stride8, void* stream);
 
-/* O[b][q][h*128 + d] = softmax_k(Q K^T) V per (batch, head); strides of Q8 / K8 in BYTES (= elements), of O in bf16 elements. */
+/* O[b][q][h*head_dim + d] = softmax_k(Q K^T) V per (batch, head), head_dim 128 or 64; strides of Q8 / K8 in BYTES (= elements), of O in
+ * bf16 elements. */
 int fw_attention_fp8(const uint8_t* Q8, int64_t ldq, int64_t bsq, const uint8_t* K8, int64_t ldk, int64_t bsk,
                      const uint8_t* Vt8, int64_t lkp, uint16_t* O, int64_t ldo, int64_t bso,
                      int batch, int heads, int head_dim, int Lq, int Lk, int q_exp, void* stream);

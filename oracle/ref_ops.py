@@ -460,7 +460,10 @@ class TorchRefOps:
         m = s.amax(dim=-1, keepdim=True)
         if self.fp8_linear_exp:      # round 6 default of the kernel: the e4m3 BYTE of P is round(8 (s - m + 7) + 56) -- 2^f ~ 1 + f inside a
             # binade, v_cvt_pk_u8_f32's round-to-nearest-even and saturation at 0 (csrc/attention_fp8.hip, tools/probes/cvt_pk_u8_probe.hip)
-            bits = torch.round(8.0 * (s - m).float() + 112.0).clamp(0, 255).to(torch.uint8)
+            # the shift is a WHOLE number of binades (the byte -> value map is exponential only from binade to binade): the largest
+            # byte of a row lands in (104, 112]
+            mq = 8.0 * torch.ceil((8.0 * m.float() - 112.0) / 8.0)
+            bits = torch.round(8.0 * s.float() - mq).clamp(0, 255).to(torch.uint8)
             pr = bits.view(torch.float8_e4m3fn).to(torch.float64)
         else:                        # FW_ATTN_VAR=12: P = e4m3(2^(s - m + 7))
             pr = torch.exp2((s - m + 7.0).float()).to(torch.float8_e4m3fn).to(torch.float64)

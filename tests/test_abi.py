@@ -68,7 +68,7 @@ def test_argument_validation_needs_no_gpu():
     bad(cg(p, 64, 64, 1, 5000, 4, 1, 3, 3, 1, 1, 1, 1, 1, 0, 1, p, 576, p, 64, 1, 64, None, 0, None, None, None, 0, 0, None), "chunk the volume")
     bad(cg(p, 64, 64, 1, 4, 4, 1, 3, 3, 1, 1, 1, 1, 1, 0, 1, p, 512, p, 64, 1, 64, None, 0, None, None, None, 0, 0, None), "ldw < taps")
     bad(lib.fw_v_transpose_fp8(p, 128, 128 * 4, p, 100, 1, 1, 128, 4, 0, None), "fw_v_transpose_fp8")         # lkp % 64 != 0
-    bad(lib.fw_attention_fp8(p, 128, 0, p, 128, 0, p, 64, p, 128, 0, 1, 1, 96, 4, 4, 3, None), "head_dim must be 128")
+    bad(lib.fw_attention_fp8(p, 128, 0, p, 128, 0, p, 64, p, 128, 0, 1, 1, 96, 4, 4, 3, None), "head_dim must be 128 or 64")
     bad(lib.fw_attention_fp8(p, 120, 0, p, 128, 0, p, 64, p, 128, 0, 1, 1, 128, 4, 4, 3, None), "alignment contract")
     bad(lib.fw_resize_bilinear(p, 60, p, 60, 1, 2, 2, 4, 4, 60, None), "fw_resize_bilinear")
     bad(lib.fw_chan_rmsnorm_silu(p, 64, p, 64, 4, 64, 100, p, 1, None), "fw_chan_rmsnorm_silu")        # c_true > C

@@ -294,10 +294,14 @@ def test_fp8_attention_engine_on_its_cpu_statement(case_l2):
     kw = forward_kwargs(case_l2)
     ins = case_l2.inputs
     outs = {}
-    for tag, opts in (("fp8_linears", dict(precision="fp8")), ("fp8_all", dict(precision="fp8", fp8_attention=True))):
+    for tag, opts in (("fp8_linears", dict(precision="fp8")), ("fp8_all", dict(precision="fp8", fp8_attention=True)),
+                      ("fp8_every_attention", dict(precision="fp8", fp8_attention="all"))):
         eng = FusionEngine(case_l2.cfg, case_l2.weights.__getitem__, TorchRefOps(), **opts)
         outs[tag], _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
     e = rel_l2(outs["fp8_all"], outs["fp8_linears"])
+    assert 0 < e < 5e-2, e
+    # fp8_attention="all" (round 6): the bicross attention (zero-padded heads) and the VGGT frame / global attention (head_dim 64) as well
+    e = rel_l2(outs["fp8_every_attention"], outs["fp8_all"])
     assert 0 < e < 5e-2, e
 
     class NoFp8Attention(TorchRefOps):

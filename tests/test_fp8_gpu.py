@@ -195,18 +195,48 @@ def test_attention_fp8_against_fp32_softmax(ops, B, H, Lq, Lk, parity, request):
     # the linear byte against the exact exponential: 1 + f for 2^f inside a binade, a +-3 % ripple on P beside e4m3's own +-3 % rounding
     # (measured 4.1e-2 at 4 tiles, 2e-2 at 64: both are realisations of the same rounding noise, they do not add up in the result)
     parity.check(f"op/{request.node.name}/linear_byte_vs_exact_exponential", rel_l2(outs[14], outs[12]), 6e-2)
-    # the two-block tile tests BOTH key blocks for overflow at one point (after S1): when the shift moves it can move by another amount
-    # than in round 5's body, and round(8 (s - M) + 56) then meets the byte grid at another offset
-    parity.check(f"op/{request.node.name}/two_block_tile_vs_round5_tile", rel_l2(outs[192], outs[14]), 4e-2)
+    # the two-block tile tests BOTH key blocks for overflow at one point (after S1), so its shift can move in another tile and by another
+    # amount than in round 5's body -- and since the shift moves by WHOLE BINADES (byte + 8 j decodes to exactly 2^j times byte's value)
+    # that changes nothing but which tiny weights fall below e4m3's range: measured 0 ... 1.9e-5 (2.3e-2 before the shift was quantised)
+    parity.check(f"op/{request.node.name}/two_block_tile_vs_round5_tile", rel_l2(outs[192], outs[14]), 1e-3)
     # against the older kernels only the fp8 noise level can be asked for: the shift M moves block by block here and tile by tile there,
     # so 2^(s - M) meets e4m3's rounding grid at another offset (another realisation of the same 3-bit rounding noise; measured 1.5-1.9e-2)
     parity.check(f"op/{request.node.name}/single_stream_vs_pingpong_kernel", rel_l2(outs[12], outs[9]), 4e-2)
-    # and the CPU statement of the same arithmetic (oracle/ref_ops.py::attention_fp8 -- true row maximum there, a lazily moved shift here:
-    # the shift changes which scores round up, so noise-level agreement, not bits)
+    # and the CPU statement of the same arithmetic (oracle/ref_ops.py::attention_fp8 -- the TRUE row maximum there, a lazily moved shift
+    # here; both whole numbers of binades, so the probabilities agree up to one power of two per row): what separates the two is the
+    # bf16 rounding of the kernel's output (1.6-1.9e-3; 3.8e-2 at 64 tiles before the shift was quantised)
     from oracle.ref_ops import TorchRefOps
     cpu = TorchRefOps(exact=True)
     stated = cpu.attention_fp8(q8.cpu(), ops.cast_fp8(k).cpu(), cpu.prepare_v_fp8(v.cpu(), H, hd, batch=B)[0], H, hd, Lk, batch=B).float()
-    parity.check(f"op/{request.node.name}/vs_cpu_statement", rel_l2(outs[192], stated), 4e-2)
+    parity.check(f"op/{request.node.name}/vs_cpu_statement", rel_l2(outs[192], stated), 5e-3)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 256, 64), (1, 3, 300, 200), (1, 1, 31, 7), (2, 3, 515, 1029), (1, 4, 1024, 4096), (3, 4, 133, 133),
+                                       (1, 16, 1565, 1565), (1, 2, 700, 1)])
+def test_attention_fp8_head_dim_64_against_fp32_softmax(ops, B, H, Lq, Lk, parity, request):
+    """Round 6: fw_attention_fp8 at head_dim 64 (the VGGT frame / global attention of BASELINE config 5): attention_fp8_hd64_kernel -- the
+    default arm of the hd-128 kernel written out for 64-byte rows (one QK^T MFMA per key block, two PV MFMAs per tile, one request per
+    wave and tile).  Same pins as at hd 128: the fp32 softmax definition with an e4m3-sized bound, the bf16 kernel as yardstick, and
+    the CPU statement of the same arithmetic; ragged query / key counts, one-tile and one-key sequences, batches."""
+    hd = 64
+    q, k, v = (rnd(B * n, H * hd, seed=s).to(torch.bfloat16).cuda() for n, s in ((Lq, 82), (Lk, 83), (Lk, 84)))
+    def aref(q, k, v):
+        import math
+        qf, kf, vf = (t.float().view(B, -1, H, hd).permute(0, 2, 1, 3) for t in (q, k, v))
+        o = torch.softmax(qf @ kf.transpose(-1, -2) / math.sqrt(hd), -1) @ vf
+        return o.permute(0, 2, 1, 3).reshape(B * Lq, H * hd)
+    want = aref(q.cpu(), k.cpu(), v.cpu())
+    q8 = ops.cast_fp8(ops.qk_prep(q.clone(), H, hd, out_scale=ops.q_scale_fp8(hd)))
+    k8 = ops.cast_fp8(k)
+    vt8, lk = ops.prepare_v_fp8(v, H, hd, batch=B)
+    got = ops.attention_fp8(q8, k8, vt8, H, hd, lk, batch=B).float().cpu()
+    again = ops.attention_fp8(q8, k8, vt8, H, hd, lk, batch=B).float().cpu()
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    parity.check(f"op/{request.node.name}/vs_fp32_softmax", rel_l2(got, want), 8e-2)
+    from oracle.ref_ops import TorchRefOps
+    cpu = TorchRefOps(exact=True)
+    stated = cpu.attention_fp8(q8.cpu(), k8.cpu(), cpu.prepare_v_fp8(v.cpu(), H, hd, batch=B)[0], H, hd, Lk, batch=B).float()
+    parity.check(f"op/{request.node.name}/vs_cpu_statement", rel_l2(got, stated), 5e-3)      # (the bf16 rounding of the kernel's output: 1.6-1.9e-3)
 
 
 @pytest.mark.parametrize("spike_key", [1021, 963, 70, 40])

@@ -342,9 +342,11 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
     torch.cuda.empty_cache()
     # round 6 experiment (opt-in): the bicross attention on e4m3 operands as well -- against the engine with fp8 DiT attention only,
     # under the same stated 2e-2: noise_pred and both streams (the VGGT stream after block 39 is what the geometry heads read)
-    if os.environ.get("FW_FULL_DEPTH_FP8_BICROSS", "0") == "1":
-        eng = install(model, ops=ops, merge_cfg=False, precision="fp8", fp8_attention="bicross")
-        assert eng.fp8_bicross
+    if os.environ.get("FW_FULL_DEPTH_FP8_BICROSS", "0") in ("1", "all"):
+        # ("all": additionally the VGGT frame / global attention on the head_dim-64 fp8 kernel -- second half of round 6)
+        mode = "all" if os.environ["FW_FULL_DEPTH_FP8_BICROSS"] == "all" else "bicross"
+        eng = install(model, ops=ops, merge_cfg=False, precision="fp8", fp8_attention=mode)
+        assert eng.fp8_bicross and eng.fp8_vggt == (mode == "all")
         try:
             got8b = {name: _hip_forward(model, eng, cfg, ins, False) for name, ins in inputs.items()}
         finally:
@@ -352,7 +354,7 @@ def test_full_depth_fp8_linears_and_fp8_attention(parity):
         del eng
         torch.cuda.empty_cache()
         for name in inputs:
-            tag = f"full_depth_fp8/wan22/{name}/fp8_bicross_vs_bf16_bicross_fp8_dit_attention_in_both"
+            tag = f"full_depth_fp8/wan22/{name}/" + ("fp8_bicross_vs_bf16_bicross_fp8_dit_attention_in_both" if mode == "bicross" else "fp8_all_attention_vs_fp8_dit_attention_only")
             (aout, _, acap), (bout, _, bcap) = got8a[name], got8b[name]
             row = {"noise_pred": parity.check(f"{tag}/noise_pred", rel_l2(bout.float(), aout.float()), FP8_ATTENTION_VS_BF16_ATTENTION_TOL)}
             for b, what in WATCH.items():

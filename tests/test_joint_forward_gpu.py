@@ -405,14 +405,19 @@ def test_hip_fp8_bicross_attention_is_measured_against_the_bf16_bicross(case_cfg
     ins = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in case.inputs.items()}
     kw = forward_kwargs(case, "cuda")
     outs = {}
-    for tag, fa in (("dit", True), ("bicross", "bicross")):
+    for tag, fa in (("dit", True), ("bicross", "bicross"), ("all", "all")):
         eng = FusionEngine(case.cfg, case.weights.__getitem__, HipOps("cuda:0"), precision="fp8", fp8_attention=fa)
+        assert eng.fp8_bicross == (fa != True) and eng.fp8_vggt == (fa == "all")
         outs[tag], _ = eng.joint_forward(ins["x"], ins["timestep"], ins["context"], **kw)
         del eng
     torch.cuda.synchronize()
-    assert torch.isfinite(outs["bicross"].float()).all()
+    assert torch.isfinite(outs["bicross"].float()).all() and torch.isfinite(outs["all"].float()).all()
     parity.check("fp8attn/cfg1/fp8_bicross_vs_bf16_bicross", rel_l2(outs["bicross"].float(), outs["dit"].float()), 2e-2)
     parity.check("fp8attn/cfg1/fp8_bicross_vs_reference_golden", rel_l2(outs["bicross"].float(), case.golden["noise_pred"]), 1e-1)
+    # fp8_attention="all" (second half of round 6): additionally the VGGT frame / global attention (hd 64) on fw_attention_fp8's
+    # head_dim-64 kernel; same record, same stated tolerance
+    parity.check("fp8attn/cfg1/fp8_all_vs_fp8_dit_attention_only", rel_l2(outs["all"].float(), outs["dit"].float()), 2e-2)
+    parity.check("fp8attn/cfg1/fp8_all_vs_reference_golden", rel_l2(outs["all"].float(), case.golden["noise_pred"]), 1e-1)
 
 
 class _ThreadComm:
