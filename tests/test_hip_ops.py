@@ -774,8 +774,7 @@ def _digest_cases(ops):
         k, v = bf(rnd(Lk, H * hd, seed=seed + 1)).cuda(), bf(rnd(Lk, H * hd, seed=seed + 2)).cuda()
         return ops.attention(q, k, v, H, hd, q_prescaled=True)
 
-    def attn8(H, Lq, Lk, seed):
-        hd = 128
+    def attn8(H, Lq, Lk, seed, hd=128):
         q = (rnd(Lq, H * hd, seed=seed) * ops.q_scale_fp8(hd)).to(torch.bfloat16).cuda()
         k, v = bf(rnd(Lk, H * hd, seed=seed + 1)).cuda(), bf(rnd(Lk, H * hd, seed=seed + 2)).cuda()
         vt8, lk = ops.prepare_v_fp8(v, H, hd)
@@ -793,6 +792,7 @@ def _digest_cases(ops):
         "attention_sp_kernel<96,577>/H3_1500x1565": lambda: attn(3, 96, 1500, 1565, 21),
         "attention_sp_kernel<64,577>/H4_1565x1565": lambda: attn(4, 64, 1565, 1565, 31),
         "attention_fp8_sp_kernel<default>/H2_2100x2100": lambda: attn8(2, 2100, 2100, 41),
+        "attention_fp8_hd64_kernel/H4_1565x1565": lambda: attn8(4, 1565, 1565, 45, hd=64),
         "gemm_bf16_two_slot_kernel/2304x1536x1024_bias_gelu_bf16": lambda: gemm(2304, 1536, 1024, 51, act="gelu_tanh"),
         "gemm_bf16_two_slot_kernel/2304x1024x2048_gate_f32_residual": lambda: gemm(2304, 1024, 2048, 61, residual=True),
         "gemm_fp8_pp_kernel/2304x1024x1024_bias_bf16": lambda: gemm(2304, 1024, 1024, 71, fp8=True),
