@@ -128,8 +128,10 @@ class TPFusionEngine(FusionEngine):
             if not tp.divides(H):
                 raise ValueError(f"{H} {name} heads do not divide over {tp.world} tensor-parallel ranks")
         self.tp = tp
+        # (fp8_attention = "bicross" / "all" are one-GPU experiments of the unsharded engine: here, as under the sequence shard, they mean
+        #  True -- the DiT self-attention of this rank's heads)
         super().__init__(cfg, get, ops, shard=None, heads_cfg=heads_cfg, cache_step_invariants=cache_step_invariants,
-                         precision=precision, fp8_attention=fp8_attention)
+                         precision=precision, fp8_attention=bool(fp8_attention))
 
     # ------------------------------------------------------------------------------------------------ packing (weight slices)
     def _pack_dit(self, b, g, lin, lin_cat, prefix=None, adapter=None):
